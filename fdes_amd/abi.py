@@ -1,0 +1,201 @@
+"""ctypes mirror of include/fdes_abi.h (the C-ABI of libFDES_SHARED_LIB.so).
+
+Host-side Python counterpart of the reference's only Python caller, Python/pyFDES.py:33-41,100
+(which `ctypes.CDLL`s the CUDA library and calls FDES(...)).  Plain data + function prototypes;
+no compute happens here and there is NO fallback: if the HIP library is missing, loading fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+FDES_STR = 1024
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libFDES_SHARED_LIB.so")
+
+_AB_NAMES = ("C1_0 C1_1 A1_0 A1_1 A2_0 A2_1 B2_0 B2_1 C3_0 C3_1 A3_0 A3_1 S3_0 S3_1 "
+             "A4_0 A4_1 B4_0 B4_1 D4_0 D4_1 C5_0 C5_1 A5_0 A5_1 R5_0 R5_1 S5_0 S5_1").split()
+
+
+class Aberration(C.Structure):
+    _fields_ = [(n, C.c_float) for n in _AB_NAMES]
+
+
+class Params(C.Structure):
+    """fdes_params (params_t without CUDA handles, include/paramStructure.h:48-162)."""
+    _fields_ = [
+        ("E0", C.c_float), ("gamma", C.c_float), ("lambda_", C.c_float), ("sigma", C.c_float),
+        ("ab", Aberration),
+        ("defocspread", C.c_float), ("illangle", C.c_float), ("mtfa", C.c_float), ("mtfb", C.c_float),
+        ("mtfc", C.c_float), ("mtfd", C.c_float), ("ObjAp", C.c_float),
+        ("mode", C.c_int32), ("m1", C.c_int32), ("m2", C.c_int32), ("m3", C.c_int32),
+        ("d1", C.c_float), ("d2", C.c_float), ("d3", C.c_float),
+        ("dn1", C.c_int32), ("dn2", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32), ("n3", C.c_int32),
+        ("frPh", C.c_int32),
+        ("pD", C.c_float), ("subSlTh", C.c_float),
+        ("tilt_offset_x", C.c_float), ("tilt_offset_y", C.c_float), ("tilt_offset_z", C.c_float),
+        ("doBeamTilt", C.c_int32), ("cap", C.c_int32),
+        ("tiltspec", C.POINTER(C.c_float)), ("tiltbeam", C.POINTER(C.c_float)), ("defoci", C.POINTER(C.c_float)),
+        ("imPot", C.c_float), ("nAt", C.c_int32),
+        ("user_name", C.c_char * FDES_STR), ("institution", C.c_char * FDES_STR),
+        ("department", C.c_char * FDES_STR), ("email", C.c_char * FDES_STR),
+        ("comments", C.c_char * FDES_STR), ("sample_name", C.c_char * FDES_STR),
+        ("material", C.c_char * FDES_STR),
+    ]
+
+
+class Atoms(C.Structure):
+    _fields_ = [("nAt", C.c_int32), ("Z", C.POINTER(C.c_int32)), ("xyz", C.POINTER(C.c_float)),
+                ("dwf", C.POINTER(C.c_float)), ("occ", C.POINTER(C.c_float))]
+
+
+class HostParams:
+    """A Params struct whose three per-measurement arrays are numpy-owned."""
+
+    def __init__(self, n3=1):
+        self.c = Params()
+        self._alloc(max(int(n3), 1))
+
+    def _alloc(self, cap):
+        self.tiltspec = np.zeros(2 * cap, np.float32)
+        self.tiltbeam = np.zeros(2 * cap, np.float32)
+        self.defoci = np.zeros(cap, np.float32)
+        self.c.cap = cap
+        self.c.tiltspec = self.tiltspec.ctypes.data_as(C.POINTER(C.c_float))
+        self.c.tiltbeam = self.tiltbeam.ctypes.data_as(C.POINTER(C.c_float))
+        self.c.defoci = self.defoci.ctypes.data_as(C.POINTER(C.c_float))
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            if k in ("tiltspec", "tiltbeam", "defoci"):
+                arr = getattr(self, k)
+                v = np.asarray(v, np.float32).ravel()
+                arr[:v.size] = v
+            elif k in _AB_NAMES:
+                setattr(self.c.ab, k, v)
+            elif k == "lambda":
+                self.c.lambda_ = v
+            else:
+                setattr(self.c, k, v)
+        return self
+
+    def copy(self):
+        q = HostParams(self.c.cap)
+        C.memmove(C.byref(q.c), C.byref(self.c), C.sizeof(Params))
+        q.tiltspec[:] = self.tiltspec
+        q.tiltbeam[:] = self.tiltbeam
+        q.defoci[:] = self.defoci
+        q.c.tiltspec = q.tiltspec.ctypes.data_as(C.POINTER(C.c_float))
+        q.c.tiltbeam = q.tiltbeam.ctypes.data_as(C.POINTER(C.c_float))
+        q.c.defoci = q.defoci.ctypes.data_as(C.POINTER(C.c_float))
+        return q
+
+    @property
+    def ptr(self):
+        return C.byref(self.c)
+
+
+class HostAtoms:
+    """fdes_atoms over numpy arrays (Z int32[n], xyz float32[n,3], dwf, occ float32[n])."""
+
+    def __init__(self, Z, xyz, dwf, occ):
+        self.Z = np.ascontiguousarray(Z, np.int32)
+        self.xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        n = self.Z.size
+        self.dwf = np.ascontiguousarray(np.broadcast_to(np.asarray(dwf, np.float32), (n,)))
+        self.occ = np.ascontiguousarray(np.broadcast_to(np.asarray(occ, np.float32), (n,)))
+        assert self.xyz.shape[0] == n
+        self.c = Atoms(n, self.Z.ctypes.data_as(C.POINTER(C.c_int32)),
+                       self.xyz.ctypes.data_as(C.POINTER(C.c_float)),
+                       self.dwf.ctypes.data_as(C.POINTER(C.c_float)),
+                       self.occ.ctypes.data_as(C.POINTER(C.c_float)))
+
+    @property
+    def n(self):
+        return int(self.Z.size)
+
+    @property
+    def ptr(self):
+        return C.byref(self.c)
+
+    def as_array6(self):
+        """flat [Z,x,y,z,DWF,occ] per atom as Python/pyFDES.py:88-98 packs it."""
+        a = np.empty((self.n, 6), np.float32)
+        a[:, 0] = self.Z
+        a[:, 1:4] = self.xyz
+        a[:, 4] = self.dwf
+        a[:, 5] = self.occ
+        return a
+
+
+# (name, restype, argtypes) of every symbol include/fdes_abi.h declares
+_P = C.POINTER
+_vp = C.c_void_p
+PROTOTYPES = [
+    ("fdes_params_init", C.c_int, [_P(Params), C.c_int]),
+    ("fdes_params_release", None, [_P(Params)]),
+    ("fdes_params_consistent", C.c_int, [_P(Params)]),
+    ("fdes_params_sub_slices", C.c_int, [_P(Params)]),
+    ("fdes_read_cnf", C.c_int, [C.c_char_p, _P(Params), _P(Atoms), C.c_int]),
+    ("fdes_write_cnf", C.c_int, [C.c_char_p, _P(Params), _P(Atoms)]),
+    ("fdes_atoms_release", None, [_P(Atoms)]),
+    ("fdes_atoms_from_array", C.c_int, [_P(Atoms), _P(C.c_float), C.c_int, C.c_int]),
+    ("fdes_write_binary", C.c_int, [C.c_char_p, _P(C.c_float), C.c_size_t]),
+    ("fdes_write_emd", C.c_int, [C.c_char_p, _P(Params), _P(Atoms), _P(C.c_float), _P(C.c_float),
+                                 _P(C.c_float), C.c_int]),
+    ("fdes_create", C.c_int, [_P(_vp), C.c_int]),
+    ("fdes_destroy", C.c_int, [_vp]),
+    ("fdes_last_error", C.c_char_p, [_vp]),
+    ("fdes_gpu_available", C.c_int, []),
+    ("fdes_build_measurements", C.c_int, [_vp, _P(Params), _P(Atoms), _P(C.c_float), _P(C.c_float),
+                                          _P(C.c_float)]),
+    ("fdes_plan_create", C.c_int, [_vp, _P(Params), _P(Atoms), _P(_vp)]),
+    ("fdes_plan_destroy", C.c_int, [_vp]),
+    ("fdes_plan_begin_measurement", C.c_int, [_vp, C.c_int]),
+    ("fdes_plan_run_config", C.c_int, [_vp, C.c_int, C.c_int, C.c_float]),
+    ("fdes_plan_end_measurement", C.c_int, [_vp, C.c_int]),
+    ("fdes_plan_intensity_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
+    ("fdes_plan_images_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
+    ("fdes_plan_get_images", C.c_int, [_vp, _P(C.c_float)]),
+    ("fdes_plan_sync", C.c_int, [_vp]),
+    ("fdes_plan_num_slices", C.c_int, [_vp]),
+    ("fdes_plan_slices_done", C.c_int64, [_vp]),
+    ("fdes_plan_slice_loop_ms", C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
+    ("fdes_plan_tap_coords", C.c_int, [_vp, C.c_int, C.c_int, _P(C.c_float)]),
+    ("fdes_plan_tap_potential", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _P(C.c_float)]),
+    ("fdes_plan_tap_wave", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _P(C.c_float)]),
+    ("fdes_plan_tap_propagator", C.c_int, [_vp, _P(C.c_float)]),
+    ("fdes_plan_propagate_dev", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
+    ("fdes_set_option", C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    ("FDES", None, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, _P(C.c_float), C.c_int,
+                    _P(C.c_float)]),
+    ("fdes_run_file", C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, _P(C.c_float),
+                                C.c_int, _P(C.c_float)]),
+    ("fdes_abi_version", C.c_int, []),
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library.  Raises (never falls back) when it is missing or a symbol that
+    include/fdes_abi.h declares is not exported."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or os.environ.get("FDES_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"fdes_amd: HIP library not built: {path} (run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C fdes_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, res, args in PROTOTYPES:
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))

@@ -1,0 +1,195 @@
+/* fdes_abi.h — C-ABI of the MI355X-native FDES forward-multislice engine.
+ *
+ * Plain C: pointers, sizes, PODs.  No torch / HIP types appear in any signature.
+ * Every entry point names the reference interface it replaces (paths relative to
+ * the FDES reference tree).  Unless stated otherwise functions return 0 on
+ * success and a negative FDES_E* code on failure; they never exit()/abort() the
+ * process (the reference does: src/FDESExport.cu:98-127, include/cuda_assert.hpp).
+ *
+ * Library: fdes_amd/csrc/libFDES_SHARED_LIB.so (name kept from
+ * Python/CMakeLists.txt:84 so that Python/pyFDES.py:36-style loaders keep working).
+ */
+#ifndef FDES_ABI_H_
+#define FDES_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDES_ABI_VERSION 1
+#define FDES_STR 1024 /* BUZZ_SIZE, include/paramStructure.h:39 */
+
+enum {
+    FDES_OK = 0,
+    FDES_EINVAL = -1,   /* bad argument / inconsistent parameters          */
+    FDES_EIO = -2,      /* file could not be read / written                */
+    FDES_EGPU = -3,     /* HIP / rocFFT runtime error (see fdes_last_error) */
+    FDES_ENOMEM = -4,
+    FDES_EUNSUPPORTED = -5
+};
+
+/* aberration_t, include/paramStructure.h:56-85 (same member order) */
+typedef struct fdes_aberration {
+    float C1_0, C1_1, A1_0, A1_1, A2_0, A2_1, B2_0, B2_1, C3_0, C3_1, A3_0, A3_1, S3_0, S3_1;
+    float A4_0, A4_1, B4_0, B4_1, D4_0, D4_1, C5_0, C5_1, A5_0, A5_1, R5_0, R5_1, S5_0, S5_1;
+} fdes_aberration;
+
+/* params_t without the CUDA handles (include/paramStructure.h:48-162).
+ * tiltspec/tiltbeam/defoci have `cap` entries (2*cap, 2*cap, cap floats) and are
+ * owned by whoever filled the pointers (fdes_params_init allocates them,
+ * fdes_params_release frees them). */
+typedef struct fdes_params {
+    /* EM_t */
+    float E0, gamma, lambda, sigma;
+    fdes_aberration ab;
+    float defocspread, illangle, mtfa, mtfb, mtfc, mtfd, ObjAp;
+    /* IM_t */
+    int32_t mode, m1, m2, m3;
+    float d1, d2, d3;
+    int32_t dn1, dn2, n1, n2, n3, frPh;
+    float pD, subSlTh;
+    float tilt_offset_x, tilt_offset_y, tilt_offset_z;
+    int32_t doBeamTilt;
+    int32_t cap;       /* capacity (in measurements) of the three arrays below */
+    float* tiltspec;   /* [2*k] -> t_0 (rotates y,z), [2*k+1] -> t_1 (rotates x,z) */
+    float* tiltbeam;
+    float* defoci;
+    /* SAMPLE_t */
+    float imPot;
+    int32_t nAt;
+    /* free text (USER_t, COMMENT_t, SAMPLE_t strings) */
+    char user_name[FDES_STR], institution[FDES_STR], department[FDES_STR], email[FDES_STR];
+    char comments[FDES_STR], sample_name[FDES_STR], material[FDES_STR];
+} fdes_params;
+
+/* Host-side atom list (what the reference keeps as four device arrays
+ * Z_d, xyzCoord_d, DWF_d, occ_d; src/paramStructure.cu:274-291). */
+typedef struct fdes_atoms {
+    int32_t nAt;
+    int32_t* Z;  /* [nAt]                      */
+    float* xyz;  /* [3*nAt] AoS x,y,z  [m]     */
+    float* dwf;  /* [nAt]  Debye-Waller [m^2]  */
+    float* occ;  /* [nAt]                      */
+} fdes_atoms;
+
+typedef struct fdes_ctx fdes_ctx;   /* one per GPU (replaces the reference's globals) */
+typedef struct fdes_plan fdes_plan; /* device-resident state of one simulation        */
+
+/* ---------------- parameters: host only, no GPU needed ---------------- */
+
+/* allocParams + defaultParams, src/paramStructure.cu:686-705, 501-598 */
+int fdes_params_init(fdes_params* p, int n3_capacity);
+void fdes_params_release(fdes_params* p);
+/* consitentParams, src/paramStructure.cu:637-673 (gamma, lambda, sigma, m=n+2dn, doBeamTilt) */
+int fdes_params_consistent(fdes_params* p);
+/* subSliceRatio + setSubSlices, src/crystalMaker.cu:720-743; returns the ratio (>=1) or <0 */
+int fdes_params_sub_slices(fdes_params* p);
+/* getParams/readConfig/numberOfAtoms/readCoordinates, src/paramStructure.cu:600-635, 42-302,
+ * 1019-1077.  flags: FDES_CNF_BUG_COMPATIBLE reproduces the reference's reader quirks
+ * (duplicated last atom, 100-byte fgets splitting, index-advancing blank lines);
+ * FDES_CNF_SKIP_ATOMS mirrors `atomsFromExternal` (src/paramStructure.cu:268). */
+#define FDES_CNF_BUG_COMPATIBLE 1
+#define FDES_CNF_SKIP_ATOMS 2
+int fdes_read_cnf(const char* file, fdes_params* p, fdes_atoms* atoms, int flags);
+/* writeConfig, src/paramStructure.cu:362-491 */
+int fdes_write_cnf(const char* file, const fdes_params* p, const fdes_atoms* atoms);
+void fdes_atoms_release(fdes_atoms* a);
+/* readAtomsFromArray, src/paramStructure.cu:304-345: flat float[6*n] = {Z,x,y,z,DWF,occ}.
+ * truncate_occ != 0 reproduces the reference's (int) cast of the occupancy (:323). */
+int fdes_atoms_from_array(fdes_atoms* a, const float* atomsArray, int numAtoms, int truncate_occ);
+/* writeBinary, src/rwBinary.cpp:44-51 */
+int fdes_write_binary(const char* file, const float* data, size_t n);
+/* writeHdf5 (results), src/rwHdf5.cu:27-1083.  libhdf5 is dlopen'ed; FDES_EUNSUPPORTED if absent. */
+int fdes_write_emd(const char* file, const fdes_params* p, const fdes_atoms* atoms,
+                   const float* image, const float* potential, const float* exitwave, int print_level);
+
+/* ---------------- engine ---------------- */
+
+/* cudaSetDevice(gpu_index), src/FDES.cu:165 */
+int fdes_create(fdes_ctx** ctx, int gpu_index);
+int fdes_destroy(fdes_ctx* ctx);
+const char* fdes_last_error(const fdes_ctx* ctx);
+/* Non-zero when HIP kernels of this library can run (a GPU is visible). */
+int fdes_gpu_available(void);
+
+/* buildMeasurements, src/crystalMaker.cu:227-424 / include/crystalMaker.h:77, with HOST
+ * pointers and without the file writing.  `p` is the consistent parameter set BEFORE
+ * sub-slicing (the call applies fdes_params_sub_slices to a private copy, as the reference
+ * does at :246-247).  image: float[n1*n2*n3], image[k*n1*n2 + i2*n1 + i1].
+ * potential (may be NULL): float[2*m1*m2*m3] original slices (print_level>0, :381-397).
+ * exitwave  (may be NULL): float[2*m1*m2*n3] (print_level>1, :347,370). */
+int fdes_build_measurements(fdes_ctx* ctx, const fdes_params* p, const fdes_atoms* atoms,
+                            float* image, float* potential, float* exitwave);
+
+/* ---- resident interface: the same loops, split so that inputs stay in HBM and the
+ * (k, j) configurations can be sharded over GPUs (src/crystalMaker.cu:324-373) ---- */
+
+/* Allocations + uploads of :245-295 (deep param copy, scratch, tilt offset, species list,
+ * RNG keys).  `p` BEFORE sub-slicing, as above. */
+int fdes_plan_create(fdes_ctx* ctx, const fdes_params* p, const fdes_atoms* atoms, fdes_plan** plan);
+int fdes_plan_destroy(fdes_plan* plan);
+/* Loop-1 head (:326-331): I = 0, exit-wave accumulator = 0, specimen tilt k. */
+int fdes_plan_begin_measurement(fdes_plan* plan, int k);
+/* Loop-2 body (:334-366) for configuration j of measurement k: incoming wave, frozen-phonon
+ * jitter (Philox keyed on (k, j, coordinate): independent of sharding), the slice loop
+ * (phaseGrating + forwardPropagation, :339-344), exit-wave post-processing by mode and
+ * I += result * weight.  The reference uses weight = 1/count (:302-304). Asynchronous. */
+int fdes_plan_run_config(fdes_plan* plan, int k, int j, float weight);
+/* addNoiseAndMtf (:372, :579-613) -> J[k]. */
+int fdes_plan_end_measurement(fdes_plan* plan, int k);
+/* Device pointer of the running intensity sum I (float2[m1*m2], .y = 0) so that the host
+ * can reduce it across ranks (RCCL) between run_config and end_measurement. */
+int fdes_plan_intensity_ptr(fdes_plan* plan, void** dev_ptr, size_t* bytes);
+/* Device pointer to J (float[n1*n2*n3]). */
+int fdes_plan_images_ptr(fdes_plan* plan, void** dev_ptr, size_t* bytes);
+/* D2H of J (:375). Synchronises. */
+int fdes_plan_get_images(fdes_plan* plan, float* image);
+int fdes_plan_sync(fdes_plan* plan);
+/* Number of (sub-)slices m3 after sub-slicing; slice-propagations done so far. */
+int fdes_plan_num_slices(const fdes_plan* plan);
+int64_t fdes_plan_slices_done(const fdes_plan* plan);
+/* Mean device time [ms] of the slice loops between the HIP events recorded by
+ * run_config since the last call (measurement). Synchronises. */
+int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
+
+/* ---- stage taps for parity tests (device results copied to HOST buffers) ---- */
+/* Atom coordinates used by configuration (k, j): tilt offset, tilt k, jitter. float[3*nAt]. */
+int fdes_plan_tap_coords(fdes_plan* plan, int k, int j, float* xyz);
+/* phaseGrating (src/crystalMaker.cu:507-536) of sub-slice s for configuration (k, j):
+ * V as float[2*m1*m2] interleaved (.x = sigma*v_z, .y = imPot part). */
+int fdes_plan_tap_potential(fdes_plan* plan, int k, int j, int s, float* V);
+/* Wave after `nslices` slices of configuration (k, j) (nslices = m3 -> exit wave), before
+ * any exit-wave post-processing. float[2*m1*m2]. */
+int fdes_plan_tap_wave(fdes_plan* plan, int k, int j, int nslices, float* psi);
+/* Band-limited Fresnel propagator as the slice loop applies it
+ * (src/multisliceSimulation.cu:594-603). float[2*m1*m2]. */
+int fdes_plan_tap_propagator(fdes_plan* plan, float* P);
+/* One propagation unit on caller-provided DEVICE buffers (micro-benchmark and parity):
+ * psi <- F^-1[ P * F[ t * psi ] ], batch wave functions of m2 x m1 float2 each;
+ * t is shared (batch stride 0) or per-wave.  (src/multisliceSimulation.cu:546-548) */
+int fdes_plan_propagate_dev(fdes_plan* plan, void* psi_dev, const void* t_dev, int batch, int t_per_wave);
+
+/* Engine options (before fdes_plan_create).  Unknown keys -> FDES_EINVAL.
+ *   "fft"        0 = auto, 1 = rocFFT, 2 = hand-written LDS FFT kernels (power-of-two grids)
+ *   "graph"      1 = replay the slice loop from a hipGraph
+ *   "seed"       frozen-phonon seed (reference: 1, src/crystalMaker.cu:292)              */
+int fdes_set_option(fdes_ctx* ctx, const char* key, int64_t value);
+
+/* ---------------- legacy symbol ---------------- */
+/* src/FDESExport.cu:59-60.  Same arguments; returns normally on error after printing to
+ * stderr (dstImage is then left untouched).  atomsArray: float[6*numAtoms]. */
+void FDES(int gpu_Index, int print_Level, char* input_name, char* image_name, char* emd_save_name,
+          float* atomsArray, int numAtoms, float* dstImage);
+/* int-returning twin of the above. */
+int fdes_run_file(int gpu_index, int print_level, const char* input_name, const char* image_name,
+                  const char* emd_name, const float* atomsArray, int numAtoms, float* dstImage);
+
+int fdes_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDES_ABI_H_ */

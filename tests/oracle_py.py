@@ -1,0 +1,212 @@
+"""ctypes loader of the CPU oracle (oracle/build/libfdes_oracle.so).  TEST INFRASTRUCTURE:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from fdes_amd.abi import Params, Atoms, HostParams, HostAtoms  # noqa: F401  (PODs only)
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "build", "libfdes_oracle.so")
+_lib = None
+_P = C.POINTER
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        build()
+    L = C.CDLL(_SO)
+    u32 = C.c_uint32
+    L.oracle_philox4x32_10.argtypes = [_P(u32), _P(u32), _P(u32)]
+    L.oracle_det_normal.restype = C.c_float
+    L.oracle_det_normal.argtypes = [u32, u32]
+    L.oracle_normal.restype = C.c_float
+    L.oracle_normal.argtypes = [u32] * 5
+    L.oracle_params_default.argtypes = [_P(Params), C.c_int]
+    L.oracle_consistent_params.argtypes = [_P(Params)]
+    L.oracle_sub_slices.argtypes = [_P(Params)]
+    L.oracle_sub_slices.restype = C.c_int
+    L.oracle_tilt_coordinates.argtypes = [_P(C.c_float), C.c_int, C.c_float, C.c_float, C.c_float]
+    L.oracle_atom_jitter.argtypes = [_P(C.c_float), _P(C.c_float), C.c_int, u32, C.c_int, C.c_int]
+    L.oracle_list_of_elements.argtypes = [_P(C.c_int), C.c_int, _P(C.c_int)]
+    L.oracle_list_of_elements.restype = C.c_int
+    L.oracle_config_coords.argtypes = [_P(Params), _P(Atoms), C.c_int, C.c_int, u32, _P(C.c_float)]
+    L.oracle_set_threads.argtypes = [C.c_int]
+    L.oracle_get_threads.restype = C.c_int
+    for suf, ct in (("f32", C.c_float), ("f64", C.c_double)):
+        R = _P(ct)
+
+        def g(n, suf=suf):
+            return getattr(L, f"oracle_{n}_{suf}")
+
+        g("fft2").argtypes = [R, C.c_int, C.c_int, C.c_int]
+        g("phase_grating").argtypes = [_P(Params), _P(C.c_float), _P(C.c_int), _P(C.c_float), C.c_int,
+                                       _P(C.c_int), C.c_int, C.c_int, R]
+        g("fresnel_propagator").argtypes = [_P(Params), R]
+        g("forward_propagation").argtypes = [_P(Params), R, R, R, R]
+        g("propagate_unit").argtypes = [_P(Params), R, R, R]
+        g("incoming_wave").argtypes = [_P(Params), C.c_int, R]
+        g("apply_lens").argtypes = [_P(Params), C.c_int, R]
+        g("diffraction_pattern").argtypes = [_P(Params), C.c_int, R]
+        g("add_noise_and_mtf").argtypes = [_P(Params), C.c_int, R, R]
+        g("wave").argtypes = [_P(Params), _P(Atoms), C.c_int, C.c_int, u32, C.c_int, R]
+        g("build_measurements").argtypes = [_P(Params), _P(Atoms), u32, R, R, R]
+        g("build_measurements").restype = C.c_int
+    _lib = L
+    return L
+
+
+def _dt(prec):
+    return (np.float32, C.c_float, "f32") if prec == "f32" else (np.float64, C.c_double, "f64")
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(_P(ct))
+
+
+def _c2buf(z, dt):
+    b = np.empty(z.shape + (2,), dt)
+    b[..., 0] = z.real
+    b[..., 1] = z.imag
+    return b
+
+
+def _buf2c(b):
+    return b[..., 0] + 1j * b[..., 1]
+
+
+def set_threads(n):
+    lib().oracle_set_threads(int(n))
+
+
+def get_threads():
+    return int(lib().oracle_get_threads())
+
+
+def fft2(f, inverse=False, prec="f32"):
+    """f: complex array [m2, m1] -> unnormalised 2-D FFT (copy)."""
+    dt, ct, suf = _dt(prec)
+    m2, m1 = f.shape
+    buf = _c2buf(f, dt)
+    getattr(lib(), f"oracle_fft2_{suf}")(_ptr(buf, ct), m1, m2, int(inverse))
+    return _buf2c(buf)
+
+
+def philox(ctr, key):
+    u32 = C.c_uint32
+    c = (u32 * 4)(*ctr)
+    k = (u32 * 2)(*key)
+    o = (u32 * 4)()
+    lib().oracle_philox4x32_10(c, k, o)
+    return list(o)
+
+
+def normal(seed, stream, k, j, i):
+    return float(lib().oracle_normal(seed, stream, k, j, i))
+
+
+def default_params(n3=1):
+    hp = HostParams(n3)
+    lib().oracle_params_default(hp.ptr, n3)
+    return hp
+
+
+def consistent(hp):
+    lib().oracle_consistent_params(hp.ptr)
+    return hp
+
+
+def sub_sliced(hp):
+    q = hp.copy()
+    ratio = lib().oracle_sub_slices(q.ptr)
+    return q, ratio
+
+
+def config_coords(hp, atoms, k, j, seed=1):
+    out = np.empty((atoms.n, 3), np.float32)
+    lib().oracle_config_coords(hp.ptr, atoms.ptr, k, j, seed, _ptr(out, C.c_float))
+    return out
+
+
+def list_of_elements(atoms):
+    zl = (C.c_int * 103)()
+    nz = lib().oracle_list_of_elements(zl, atoms.n, atoms.Z.ctypes.data_as(_P(C.c_int)))
+    return list(zl)[:nz]
+
+
+def phase_grating(hp_sub, atoms, xyz, s, prec="f32"):
+    """V (complex [m2, m1]) of sub-slice s for coordinates xyz. hp_sub: already sub-sliced."""
+    dt, ct, suf = _dt(prec)
+    zl = list_of_elements(atoms)
+    zarr = (C.c_int * 103)(*zl)
+    m1, m2 = hp_sub.c.m1, hp_sub.c.m2
+    V = np.zeros((m2, m1, 2), dt)
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    getattr(lib(), f"oracle_phase_grating_{suf}")(hp_sub.ptr, _ptr(xyz, C.c_float),
+                                                  atoms.Z.ctypes.data_as(_P(C.c_int)),
+                                                  _ptr(atoms.occ, C.c_float), atoms.n, zarr, len(zl), s,
+                                                  _ptr(V, ct))
+    return _buf2c(V)
+
+
+def fresnel_propagator(hp_sub, prec="f32"):
+    dt, ct, suf = _dt(prec)
+    P = np.zeros((hp_sub.c.m2, hp_sub.c.m1, 2), dt)
+    getattr(lib(), f"oracle_fresnel_propagator_{suf}")(hp_sub.ptr, _ptr(P, ct))
+    return _buf2c(P)
+
+
+def propagate_unit(hp_sub, psi, t, P, prec="f32"):
+    dt, ct, suf = _dt(prec)
+    a, b, c = _c2buf(psi, dt), _c2buf(t, dt), _c2buf(P, dt)
+    getattr(lib(), f"oracle_propagate_unit_{suf}")(hp_sub.ptr, _ptr(a, ct), _ptr(b, ct), _ptr(c, ct))
+    return _buf2c(a)
+
+
+def forward_propagation(hp_sub, psi, V, prec="f32"):
+    dt, ct, suf = _dt(prec)
+    a, v = _c2buf(psi, dt), _c2buf(V, dt)
+    fr = np.zeros_like(a)
+    t = np.zeros_like(a)
+    getattr(lib(), f"oracle_forward_propagation_{suf}")(hp_sub.ptr, _ptr(a, ct), _ptr(v, ct), _ptr(fr, ct),
+                                                        _ptr(t, ct))
+    return _buf2c(a)
+
+
+def incoming_wave(hp_sub, k, prec="f32"):
+    dt, ct, suf = _dt(prec)
+    a = np.zeros((hp_sub.c.m2, hp_sub.c.m1, 2), dt)
+    getattr(lib(), f"oracle_incoming_wave_{suf}")(hp_sub.ptr, k, _ptr(a, ct))
+    return _buf2c(a)
+
+
+def wave(hp_sub, atoms, k, j, nslices=None, seed=1, prec="f32"):
+    dt, ct, suf = _dt(prec)
+    if nslices is None:
+        nslices = hp_sub.c.m3
+    a = np.zeros((hp_sub.c.m2, hp_sub.c.m1, 2), dt)
+    getattr(lib(), f"oracle_wave_{suf}")(hp_sub.ptr, atoms.ptr, k, j, seed, nslices, _ptr(a, ct))
+    return _buf2c(a)
+
+
+def build_measurements(hp, atoms, seed=1, prec="f32", want_potential=False, want_exitwave=False):
+    """hp: consistent params BEFORE sub-slicing. Returns dict(image[n3,n2,n1], ...)."""
+    dt, ct, suf = _dt(prec)
+    c = hp.c
+    img = np.zeros((c.n3, c.n2, c.n1), dt)
+    pot = np.zeros((c.m3, c.m2, c.m1, 2), dt) if want_potential else None
+    ew = np.zeros((c.n3, c.m2, c.m1, 2), dt) if want_exitwave else None
+    null = _P(ct)()
+    n = getattr(lib(), f"oracle_build_measurements_{suf}")(
+        hp.ptr, atoms.ptr, seed, _ptr(img, ct), _ptr(pot, ct) if want_potential else null,
+        _ptr(ew, ct) if want_exitwave else null)
+    return {"image": img, "potential": pot, "exitwave": ew, "nprop": n}

@@ -1,0 +1,111 @@
+"""Deterministic specimen / parameter generators for the concrete bench and parity inputs of
+SURVEY.md 8(d') (C1..C5) plus small variants.  Lengths in metres.  Pure numpy; no reference code."""
+import numpy as np
+
+from fdes_amd.abi import HostAtoms, HostParams
+
+A_AU = 2.0393e-10  # FCC sites (i,j,l)*A_AU with i+j+l even
+
+
+def au_cuboctahedron(k):
+    """FCC Au cuboctahedron: sites (i,j,l)*2.0393e-10, i+j+l even, max(|.|) <= k, |i|+|j|+|l| <= 2k.
+    k=4 -> the shipped Au-309 particle (ExampleSpecimens/Au_cubeoctahedron_cnf), k=30 -> 94 611 atoms."""
+    r = np.arange(-k, k + 1)
+    i, j, l = np.meshgrid(r, r, r, indexing="ij")
+    keep = ((i + j + l) % 2 == 0) & (np.abs(i) + np.abs(j) + np.abs(l) <= 2 * k)
+    pts = np.stack([i[keep], j[keep], l[keep]], axis=1).astype(np.float64) * A_AU
+    return pts.astype(np.float32)
+
+
+def srtio3(ncx, ncy, ncz, a=3.905e-10):
+    """SrTiO3 cells (bin/SrTiO3.cfg): Sr(0,0,0) Ti(.5,.5,.5) O(0,.5,.5),(.5,0,.5),(.5,.5,0); replicated from
+    the cell corner then shifted by -(max-min)/2 per axis as src/rwQsc.cu:1041-1083 does."""
+    base = [(38, 0, 0, 0, 0.6214), (22, .5, .5, .5, 0.4390), (8, 0, .5, .5, 0.7323), (8, .5, 0, .5, 0.7323),
+            (8, .5, .5, 0, 0.7323)]
+    Z, xyz, dwf = [], [], []
+    for cx in range(ncx):
+        for cy in range(ncy):
+            for cz in range(ncz):
+                for (z, fx, fy, fz, b) in base:
+                    Z.append(z)
+                    xyz.append(((cx + fx) * a, (cy + fy) * a, (cz + fz) * a))
+                    dwf.append(b * 1e-20)
+    xyz = np.array(xyz, np.float64)
+    xyz -= xyz.min(axis=0)
+    xyz -= (xyz.max(axis=0) - xyz.min(axis=0)) / 2
+    return np.array(Z, np.int32), xyz.astype(np.float32), np.array(dwf, np.float32)
+
+
+def make_params(n3=1, **kw):
+    """defaultParams (src/paramStructure.cu:501-598) as data + overrides.  Derived fields (gamma, lambda,
+    sigma, m1, m2, doBeamTilt) are filled by consistency (library or oracle)."""
+    hp = HostParams(n3)
+    hp.set(E0=200e3, gamma=1.3913902, lambda_=2.507934e-12, sigma=7288400.5, C1_0=-6.1334e-8, C3_0=1e-3,
+           mtfa=1.0, ObjAp=11.1e-3, m1=4, m2=4, m3=1, d1=0.25e-10, d2=0.25e-10, d3=2e-10, subSlTh=2e-10,
+           dn1=1, dn2=1, n1=2, n2=2, n3=n3)
+    hp.set(**kw)
+    return hp
+
+
+def case_tiny(m=64, m3=4, nz=2, frPh=0, mode=0, n3=1, seed=3, tilt=False, beam_tilt=False, pD=0.0,
+              imPot=0.05, rect=False, nat=40, sub=1):
+    """Small random multi-species specimen on an m x m (rect: m x m/2) grid for fast parity tests."""
+    rng = np.random.default_rng(seed)
+    m1 = m
+    m2 = m // 2 if rect else m
+    dn1, dn2 = m1 // 4, m2 // 4
+    d = 0.2e-10
+    Zs = np.array([79, 14, 8, 38][:nz], np.int32)
+    Z = Zs[rng.integers(0, nz, nat)]
+    ext = np.array([m1 * d * 0.35, m2 * d * 0.35, m3 * 1.0e-10 * 0.5])
+    xyz = (rng.uniform(-1, 1, (nat, 3)) * ext).astype(np.float32)
+    hp = make_params(n3, E0=80e3, n1=m1 - 2 * dn1, n2=m2 - 2 * dn2, dn1=dn1, dn2=dn2, d1=d, d2=d, m3=m3,
+                     d3=1.0e-10, subSlTh=1.0e-10 / sub, frPh=frPh, mode=mode, pD=pD, imPot=imPot, C1_0=-2e-9,
+                     C3_0=1e-5, ObjAp=0.03, defocspread=2e-9, illangle=1e-4, mtfa=0.58, mtfb=0.42, mtfc=2.7,
+                     mtfd=15.5)
+    if tilt:
+        hp.set(tiltspec=rng.uniform(-0.05, 0.05, 2 * n3), tilt_offset_x=0.17, tilt_offset_z=0.26)
+    if beam_tilt:
+        hp.set(tiltbeam=rng.uniform(-5e-3, 5e-3, 2 * n3))
+    hp.set(defoci=rng.uniform(-5e-9, 5e-9, n3))
+    atoms = HostAtoms(Z, xyz, np.full(nat, 6e-21, np.float32), rng.uniform(0.5, 1.0, nat).astype(np.float32))
+    return hp, atoms
+
+
+def case_c1():
+    """C1: SrTiO3 3x3x4 cells, 256^2 wave, 8 slices (CPU-runnable reference-sized case)."""
+    Z, xyz, dwf = srtio3(3, 3, 4)
+    n = 128
+    hp = make_params(1, E0=200e3, n1=n, n2=n, dn1=64, dn2=64, d1=3 * 3.905e-10 / n, d2=3 * 3.905e-10 / n,
+                     m3=8, d3=1.9525e-10, subSlTh=1.9525e-10, mode=0, frPh=0, pD=0.0, imPot=0.1, ObjAp=20e-3)
+    return hp, HostAtoms(Z, xyz, dwf, 1.0)
+
+
+def case_c3(k=30, n=1024, dn=512, m3=256, frPh=32):
+    """C3 (headline): Au cuboctahedron, 2048^2 wave, 256 slices, 32 frozen-phonon configs."""
+    xyz = au_cuboctahedron(k)
+    hp = make_params(1, E0=50e3, n1=n, n2=n, dn1=dn, dn2=dn, d1=0.25e-10, d2=0.25e-10, m3=m3, d3=1.0e-10,
+                     subSlTh=1.0e-10, mode=0, frPh=frPh, pD=0.0, tilt_offset_x=0.17, tilt_offset_y=0.0,
+                     tilt_offset_z=0.26, ObjAp=11.1e-3)
+    return hp, HostAtoms(np.full(len(xyz), 79, np.int32), xyz, 6e-21, 1.0)
+
+
+def case_c4(n3=64, frPh=8, n=512, dn=256, cells=(9, 9, 20)):
+    """C4: SrTiO3 beam-tilt series, 1024^2 wave, 40 slices."""
+    Z, xyz, dwf = srtio3(*cells)
+    d = cells[0] * 3.905e-10 / n
+    g = int(round(np.sqrt(n3)))
+    tx, ty = np.meshgrid(np.linspace(-10e-3, 10e-3, g), np.linspace(-10e-3, 10e-3, max(n3 // g, 1)))
+    tb = np.stack([tx.ravel(), ty.ravel()], 1)[:n3].ravel()
+    hp = make_params(n3, E0=200e3, n1=n, n2=n, dn1=dn, dn2=dn, d1=d, d2=d, m3=2 * cells[2], d3=1.9525e-10,
+                     subSlTh=1.9525e-10, mode=0, frPh=frPh, pD=0.0, imPot=0.1, ObjAp=20e-3)
+    hp.set(tiltbeam=tb)
+    return hp, HostAtoms(Z, xyz, dwf, 1.0)
+
+
+def case_c5(k=60, frPh=16):
+    """C5: 4096^2 wave, 512 slices (HBM-bound stress)."""
+    xyz = au_cuboctahedron(k)
+    hp = make_params(1, E0=50e3, n1=2048, n2=2048, dn1=1024, dn2=1024, d1=0.25e-10, d2=0.25e-10, m3=512,
+                     d3=0.5e-10, subSlTh=0.5e-10, mode=0, frPh=frPh, pD=0.0)
+    return hp, HostAtoms(np.full(len(xyz), 79, np.int32), xyz, 6e-21, 1.0)
