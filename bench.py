@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py — slice-propagations/s of the FDES forward path on MI355X (BASELINE.json metric).
+
+Workload (config C3 of SURVEY.md 8d', BASELINE.json configs[2]): Au cuboctahedron (94 611 atoms, generator
+tests/specimens.py), 2048 x 2048 wave, 256 slices, frozen-phonon configurations.  One STEP = the whole slice
+loop (projected-potential build + band-limited transmission + Fresnel propagation, 256 slice-propagations)
+plus exit-wave post-processing of ONE frozen-phonon configuration per rank, inputs resident in HBM.  Ranks
+take different configurations j (weak scaling, no data-path collective); after the timed region the partial
+intensity sums are all-reduced once over RCCL (the "trivial gather" of the north star).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel class (the 2-D FFT, 6 per slice),
+timed live with HIP events on the engine's stream; `cpu_baseline` is the CPU oracle (our restatement; the
+reference has no CPU path) on a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=2048, help="wave size m (m x m), default the headline 2048")
+    ap.add_argument("--slices", type=int, default=256)
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--fft", type=int, default=0, help="engine option fft: 0 auto, 1 rocFFT, 2 hand-written")
+    ap.add_argument("--probe-stride", type=int, default=8)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+
+    import fdes_amd
+    from tests import specimens
+
+    m = args.size
+    k_au = 30 if m >= 2048 else max(2, int(30 * m / 2048))
+    hp, atoms = specimens.case_c3(k=k_au, n=m // 2, dn=m // 4, m3=args.slices, frPh=32)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(local, fft=args.fft, probe_stride=args.probe_stride)
+    plan = eng.plan(hp, atoms)
+    m3 = plan.m3
+    weight = 1.0 / 32.0
+
+    def barrier():
+        plan.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    plan.begin_measurement(0)
+    for w in range(args.warmup):
+        plan.run_config(0, 1000 + rank + world * w, 0.0)  # untimed, weight 0: does not touch the sum
+    plan.sync()
+    plan.slice_loop_ms()
+    plan.probe_ms()
+
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        plan.run_config(0, rank + world * s, weight)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    loop_ms, loop_slices = plan.slice_loop_ms()
+    fft_ms, fft_n = plan.probe_ms()
+
+    # after the timed region: one all-reduce of the partial intensity sums, finalise on rank 0
+    if world > 1:
+        ptr, nbytes = plan.intensity_ptr()
+        buf = torch.empty(nbytes // 4, device="cuda", dtype=torch.float32)
+        plan.copy_intensity(buf.data_ptr(), 0)
+        dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        plan.copy_intensity(buf.data_ptr(), 1)
+    plan.end_measurement(0)
+    img = plan.get_images()
+    finite = bool(np.isfinite(img).all())
+
+    total_slices = world * args.steps * m3
+    value = total_slices / dt
+    px = m * m
+    roof = None
+    fused = plan.fft_backend() == 2
+    if fft_n > 0:
+        per_launch_s = fft_ms / fft_n * 1e-3
+        if fused:
+            # dominant kernel = one LDS row pass; the probed one is P6 (y FFT, * propagator table, y IFFT):
+            # 8 B/px wave in + 8 B/px table in + 8 B/px wave out ("P multiply fused into the IFFT pass")
+            kname, alg_bytes = f"k_pass<{m}, FWD, PTAB, INV, transposed> (P6 of 6 passes/slice)", 24.0 * px
+        else:
+            # one rocFFT 2-D C2C = 2 passes x (8 B read + 8 B write) per pixel ("FFT pass 16 B/px")
+            kname, alg_bytes = f"rocFFT 2-D C2C {m}x{m} (row + column kernels)", 32.0 * px
+        ach = alg_bytes / per_launch_s / 1e9
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": int(fft_n),
+                "algorithmic_bytes_per_launch": alg_bytes}
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_baseline:
+        cpu = cpu_baseline(hp, atoms, m)
+
+    if rank == 0:
+        out = {
+            "metric": "slice-propagations/sec", "value": round(value, 2), "unit": "slice-propagations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3 Au cuboctahedron k={k_au} ({atoms.n} atoms), {m}x{m} wave, {m3} slices, "
+                                   f"1 frozen-phonon configuration per step per GPU (of 32), mode 0",
+                       "wave": [m, m], "slices": m3, "atoms": atoms.n, "configs_per_step": world,
+                       "parallelism": f"configs sharded over {world} GPU(s)"},
+            "device_slice_loop_ms_per_slice": round(loop_ms / max(loop_slices, 1), 5),
+            "full_step_algorithmic_GBps": round((176 + 56 * 1) * px * (loop_slices / max(loop_ms, 1e-9) * 1e3) / 1e9, 1),
+            "slice_loop": "fused LDS passes" if fused else "rocFFT + point-wise kernels",
+            "roofline": roof, "cpu_baseline": cpu, "finite": finite,
+        }
+        print(json.dumps(out), flush=True)
+    plan.close()
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(hp, atoms, m):
+    """CPU oracle (kind "port": our C restatement of the reference's CUDA algorithm, float32, OpenMP) on a
+    bounded sample of the same workload: the first `ns` slices of configuration (0, 0)."""
+    from tests import oracle_py
+    q, _ = oracle_py.sub_sliced(hp)
+    cores = oracle_py.get_threads()
+    ns = 2 if m >= 4096 else (6 if m >= 2048 else 24)
+    oracle_py.wave(q, atoms, 0, 0, nslices=1)  # warm (FFT plans, page faults)
+    t0 = time.perf_counter()
+    oracle_py.wave(q, atoms, 0, 0, nslices=ns)
+    dt = time.perf_counter() - t0
+    return {"value": round(ns / dt, 3), "unit": "slice-propagations/s", "cores": cores, "kind": "port",
+            "sample": f"first {ns} slices of one {m}x{m} configuration ({dt:.1f} s incl. jitter + incoming wave)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,8 @@
+"""fdes_amd — MI355X-native forward multislice engine behind the FDES input/output surface.
+
+The product is the HIP shared library fdes_amd/csrc/libFDES_SHARED_LIB.so (C-ABI: include/fdes_abi.h);
+this package is its ctypes host binding.  Nothing here computes: if the library is not built, every
+entry point raises.
+"""
+from .abi import HostAtoms, HostParams, load_library  # noqa: F401
+from .api import Engine, FdesError, Plan, consistent, gpu_available, read_cnf, run_file, sub_sliced, write_cnf  # noqa: F401

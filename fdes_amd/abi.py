@@ -102,8 +102,8 @@ class HostAtoms:
         self.Z = np.ascontiguousarray(Z, np.int32)
         self.xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         n = self.Z.size
-        self.dwf = np.ascontiguousarray(np.broadcast_to(np.asarray(dwf, np.float32), (n,)))
-        self.occ = np.ascontiguousarray(np.broadcast_to(np.asarray(occ, np.float32), (n,)))
+        self.dwf = np.array(np.broadcast_to(np.asarray(dwf, np.float32), (n,)), np.float32)
+        self.occ = np.array(np.broadcast_to(np.asarray(occ, np.float32), (n,)), np.float32)
         assert self.xyz.shape[0] == n
         self.c = Atoms(n, self.Z.ctypes.data_as(C.POINTER(C.c_int32)),
                        self.xyz.ctypes.data_as(C.POINTER(C.c_float)),
@@ -155,17 +155,21 @@ PROTOTYPES = [
     ("fdes_plan_run_config", C.c_int, [_vp, C.c_int, C.c_int, C.c_float]),
     ("fdes_plan_end_measurement", C.c_int, [_vp, C.c_int]),
     ("fdes_plan_intensity_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
+    ("fdes_plan_copy_intensity", C.c_int, [_vp, _vp, C.c_int]),
     ("fdes_plan_images_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
     ("fdes_plan_get_images", C.c_int, [_vp, _P(C.c_float)]),
     ("fdes_plan_sync", C.c_int, [_vp]),
+    ("fdes_plan_fft_backend", C.c_int, [_vp]),
     ("fdes_plan_num_slices", C.c_int, [_vp]),
     ("fdes_plan_slices_done", C.c_int64, [_vp]),
     ("fdes_plan_slice_loop_ms", C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
+    ("fdes_plan_probe_ms", C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
     ("fdes_plan_tap_coords", C.c_int, [_vp, C.c_int, C.c_int, _P(C.c_float)]),
     ("fdes_plan_tap_potential", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _P(C.c_float)]),
     ("fdes_plan_tap_wave", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _P(C.c_float)]),
     ("fdes_plan_tap_propagator", C.c_int, [_vp, _P(C.c_float)]),
     ("fdes_plan_propagate_dev", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
+    ("fdes_fft2d_host", C.c_int, [_vp, _P(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int]),
     ("fdes_set_option", C.c_int, [_vp, C.c_char_p, C.c_int64]),
     ("FDES", None, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, _P(C.c_float), C.c_int,
                     _P(C.c_float)]),

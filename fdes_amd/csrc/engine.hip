@@ -1,0 +1,838 @@
+// engine.hip — host driver of the MI355X FDES engine: context, plan, slice loop, C-ABI.
+//
+// Restates the control flow of buildMeasurements / phaseGrating / forwardPropagation /
+// incomingWave / applyLensFunction / diffractionPattern / addNoiseAndMtf
+// (src/crystalMaker.cu:227-424, 507-536, 579-613, 700-718; src/multisliceSimulation.cu:538-622)
+// on one HIP stream, with all scratch allocated once per plan (the reference cudaMalloc/cudaFree's
+// two grids per slice, :516-517,534-535, and prints to stderr inside the slice loop, :341).
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fdes_internal.h"
+#include "fft.h"
+#include "fft_lds.h"
+#include "geometry.h"
+#include "kernels.h"
+
+using namespace fdes;
+
+struct fdes_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int opt_fft = 0;   // 0 auto, 1 rocFFT, 2 hand-written
+    int opt_graph = 0;
+    uint32_t seed = 1; // src/crystalMaker.cu:292
+    int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
+    std::map<std::pair<int, int>, Fft2D*> fft_cache; // plans are expensive to create: one per grid size
+};
+
+struct EvPair { hipEvent_t a, b; int slices; };
+
+struct fdes_plan {
+    fdes_ctx* ctx = nullptr;
+    fdes_params p0{};  // as given (before sub-slicing), own arrays
+    fdes_params p{};   // sub-sliced, shares p0's arrays
+    int ratio = 1;
+    KP kp{};
+    int nAt = 0, nZ = 0;
+    int Zlist[103];
+    std::vector<Kirk> kz;
+    // atoms
+    int32_t* Z_d = nullptr;
+    uint8_t* spec_d = nullptr;
+    float *xyz0_d = nullptr, *xyzTO_d = nullptr, *xyzK_d = nullptr, *xyzFP_d = nullptr, *dwf_d = nullptr, *occ_d = nullptr;
+    int cur_k = -1;
+    AtomBins bins;
+    int bins_cap_keys = 0;
+    int deposit_blocks = 1;
+    // grids
+    size_t m12 = 0;
+    float2 *D = nullptr, *VH = nullptr, *T = nullptr, *PSI = nullptr, *P = nullptr, *I = nullptr, *EW = nullptr;
+    float* J = nullptr;
+    float* scal = nullptr;
+    Fft2D* fft = nullptr; // owned by the context's cache
+    // fused LDS-pass slice loop (power-of-two grids): spectra in transposed ("T", [kx][y|ky]) and mixed
+    // ("N", [y][kx]) layouts, tables in T layout
+    bool fused = false;
+    float2 *A = nullptr, *B = nullptr, *C = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
+    float* GT = nullptr;
+    std::vector<EvPair> probe;
+    size_t probe_used = 0;
+    uint64_t fft_calls = 0;
+    bool want_ew = false;
+    // timing
+    std::vector<EvPair> evs;
+    size_t ev_used = 0;
+    int64_t slices_done = 0;
+};
+
+namespace {
+
+std::once_flag g_rocfft_once;
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_) + " @" + __FILE__ + ":" + std::to_string(__LINE__); \
+            return FDES_EGPU;                                                                     \
+        }                                                                                         \
+    } while (0)
+#define RC(expr)                \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_ != FDES_OK) return rc_; \
+    } while (0)
+
+// 2-D FFT of one grid, optionally bracketed by events (sampled) for the roofline measurement.
+hipError_t fft_exec(fdes_plan* pl, float2* data, bool inverse, hipStream_t st)
+{
+    fdes_ctx* c = pl->ctx;
+    const bool probe = c->probe_stride > 0 && (pl->fft_calls++ % (uint64_t)c->probe_stride) == 0;
+    EvPair* ev = nullptr;
+    if (probe) {
+        if (pl->probe_used == pl->probe.size()) {
+            EvPair e{};
+            hipError_t r = hipEventCreate(&e.a);
+            if (r != hipSuccess) return r;
+            r = hipEventCreate(&e.b);
+            if (r != hipSuccess) return r;
+            pl->probe.push_back(e);
+        }
+        ev = &pl->probe[pl->probe_used++];
+        hipError_t r = hipEventRecord(ev->a, st);
+        if (r != hipSuccess) return r;
+    }
+    hipError_t r = pl->fft->exec(data, inverse, st);
+    if (r != hipSuccess) return r;
+    if (ev) r = hipEventRecord(ev->b, st);
+    return r;
+}
+
+KP make_kp(const fdes_params& p)
+{
+    KP k{};
+    k.m1 = p.m1; k.m2 = p.m2; k.m3 = p.m3; k.n1 = p.n1; k.n2 = p.n2; k.dn1 = p.dn1; k.dn2 = p.dn2; k.mode = p.mode;
+    k.d1 = p.d1; k.d2 = p.d2; k.d3 = p.d3; k.lambda = p.lambda; k.sigma = p.sigma; k.imPot = p.imPot;
+    k.defocspread = p.defocspread; k.illangle = p.illangle; k.mtfa = p.mtfa; k.mtfb = p.mtfb; k.mtfc = p.mtfc;
+    k.mtfd = p.mtfd; k.ObjAp = p.ObjAp; k.ab = p.ab;
+    return k;
+}
+
+template <class T> int dmalloc(fdes_ctx* c, T** p, size_t n)
+{
+    HIPCHK(c, hipMalloc((void**)p, sizeof(T) * (n > 0 ? n : 1)));
+    return FDES_OK;
+}
+
+// tiltCoordinates, src/crystalMaker.cu:427-454.  cos/sin on the host, as the reference.
+int tilt_coordinates(fdes_plan* pl, float* xyz, float t_0, float t_1, float t_2)
+{
+    hipStream_t st = pl->ctx->stream;
+    if (fabsf(t_2) > FLT_EPSILON) HIPCHK(pl->ctx, geom_srot(xyz, pl->nAt, 0, 1, cosf(t_2), -sinf(t_2), st));
+    if (fabsf(t_1) > FLT_EPSILON) HIPCHK(pl->ctx, geom_srot(xyz, pl->nAt, 0, 2, cosf(t_1), -sinf(t_1), st));
+    if (fabsf(t_0) > FLT_EPSILON) HIPCHK(pl->ctx, geom_srot(xyz, pl->nAt, 1, 2, cosf(t_0), -sinf(t_0), st));
+    return FDES_OK;
+}
+
+// src/crystalMaker.cu:330-331
+int ensure_tilt(fdes_plan* pl, int k)
+{
+    if (pl->cur_k == k) return FDES_OK;
+    HIPCHK(pl->ctx, hipMemcpyAsync(pl->xyzK_d, pl->xyzTO_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, pl->ctx->stream));
+    RC(tilt_coordinates(pl, pl->xyzK_d, pl->p.tiltspec[2 * k], pl->p.tiltspec[2 * k + 1], 0.f));
+    pl->cur_k = k;
+    return FDES_OK;
+}
+
+// src/crystalMaker.cu:335-337 + the per-configuration (slice, species) binning
+int config_atoms(fdes_plan* pl, int k, int j)
+{
+    fdes_ctx* c = pl->ctx;
+    RC(ensure_tilt(pl, k));
+    if (pl->p.frPh > 0)
+        HIPCHK(c, geom_jitter(pl->xyzFP_d, pl->xyzK_d, pl->dwf_d, pl->nAt, c->seed, k, j, c->stream));
+    else
+        HIPCHK(c, hipMemcpyAsync(pl->xyzFP_d, pl->xyzK_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, c->stream));
+    BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
+    HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->nAt, g, pl->bins, c->stream));
+    return FDES_OK;
+}
+
+// bandwidthLimit, src/multisliceSimulation.cu:552-560
+int bandwidth_limit(fdes_plan* pl, float2* f)
+{
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, fft_exec(pl,f, false, c->stream));
+    HIPCHK(c, k_mask_scale(f, pl->p.m1, pl->p.m2, 1.f / ((float)pl->m12), c->stream));
+    HIPCHK(c, fft_exec(pl,f, true, c->stream));
+    return FDES_OK;
+}
+
+// phaseGrating, src/crystalMaker.cu:507-536 -> VH (real space potential of sub-slice s)
+int phase_grating(fdes_plan* pl, const float* xyz, const BinGeom& g, int s)
+{
+    fdes_ctx* c = pl->ctx;
+    KP kp = pl->kp;
+    kp.m3 = g.m3;
+    kp.d3 = g.d3;
+    for (int z = 0; z < pl->nZ; z++) {
+        HIPCHK(c, geom_deposit(pl->D, xyz, pl->occ_d, pl->bins, s * pl->nZ + z, g, pl->p.imPot, pl->deposit_blocks, c->stream));
+        HIPCHK(c, fft_exec(pl,pl->D, false, c->stream));
+        HIPCHK(c, k_filter_accum(pl->VH, pl->D, kp, pl->kz[z], z == 0, c->stream));
+    }
+    HIPCHK(c, fft_exec(pl,pl->VH, true, c->stream));
+    return FDES_OK;
+}
+
+// forwardPropagation, src/multisliceSimulation.cu:538-549 (V in VH)
+int forward_propagation(fdes_plan* pl)
+{
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, k_transmit(pl->T, pl->VH, pl->m12, c->stream));
+    RC(bandwidth_limit(pl, pl->T));
+    HIPCHK(c, k_mul(pl->PSI, pl->T, pl->PSI, pl->m12, c->stream));      // multiplyElementwise(t, psi)
+    HIPCHK(c, fft_exec(pl,pl->PSI, false, c->stream));                  // convolveWithFrProp
+    HIPCHK(c, k_mul(pl->PSI, pl->PSI, pl->P, pl->m12, c->stream));
+    HIPCHK(c, fft_exec(pl,pl->PSI, true, c->stream));
+    return FDES_OK;
+}
+
+// ---- fused slice loop: six LDS row passes per slice, no stand-alone point-wise kernel.
+//   P1  D[y][x]        -FFT_x->                          A_z[kx][y]      (per species; clears D)
+//   P2  A_z[kx][y]     -FFT_y, * G_z, sum_z, IFFT_y->    B[y][kx]
+//   P3  B[y][kx]       -IFFT_x, exp(iV), FFT_x->         C[kx][y]
+//   P4  C[kx][y]       -FFT_y, band limit / m12, IFFT_y-> E[y][kx]
+//   P5  E, PSIH[y][kx] -IFFT_x both, t * psi, FFT_x->    F[kx][y]
+//   P6  F[kx][y]       -FFT_y, * P, IFFT_y->             PSIH[y][kx]
+PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; return a; }
+PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; return a; }
+
+int fused_potential_spectrum(fdes_plan* pl, const float* xyz, const BinGeom& g, int s)
+{
+    fdes_ctx* c = pl->ctx;
+    const int m1 = pl->p.m1, m2 = pl->p.m2;
+    for (int z = 0; z < pl->nZ; z++) {
+        HIPCHK(c, geom_deposit(pl->D, xyz, pl->occ_d, pl->bins, s * pl->nZ + z, g, pl->p.imPot, pl->deposit_blocks, c->stream));
+        PassArgs a = pass_x(pl);
+        a.in0 = pl->D; a.zsrc = pl->D; a.out = pl->A + (size_t)z * pl->m12;
+        HIPCHK(c, lds_pass(m1, XF_FWD, MID_ZSRC, XF_NONE, true, a, c->stream));
+    }
+    PassArgs b = pass_y(pl);
+    b.in0 = pl->A; b.gtab = pl->GT; b.out = pl->B; b.nspecies = pl->nZ; b.species_stride = pl->m12;
+    HIPCHK(c, lds_pass(m2, XF_FWD, pl->nZ == 1 ? MID_GTAB : MID_GTABN, XF_INV, true, b, c->stream));
+    return FDES_OK;
+}
+
+int fused_slice(fdes_plan* pl, const float* xyz, const BinGeom& g, int s)
+{
+    fdes_ctx* c = pl->ctx;
+    const int m1 = pl->p.m1, m2 = pl->p.m2;
+    RC(fused_potential_spectrum(pl, xyz, g, s));
+    PassArgs a3 = pass_x(pl);
+    a3.in0 = pl->B; a3.out = pl->C;
+    HIPCHK(c, lds_pass(m1, XF_INV, MID_EXPIV, XF_FWD, true, a3, c->stream));
+    PassArgs a4 = pass_y(pl);
+    a4.in0 = pl->C; a4.out = pl->E; a4.scale = 1.f / ((float)pl->m12); a4.mindim = m1 < m2 ? m1 : m2;
+    HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, c->stream));
+    PassArgs a5 = pass_x(pl);
+    a5.in0 = pl->E; a5.in1 = pl->PSIH; a5.out = pl->F;
+    HIPCHK(c, lds_pass(m1, XF_INV, MID_MULPSI, XF_FWD, true, a5, c->stream));
+    PassArgs a6 = pass_y(pl);
+    a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->PSIH;
+    const bool probe = c->probe_stride > 0 && (pl->fft_calls++ % (uint64_t)c->probe_stride) == 0;
+    EvPair* ev = nullptr;
+    if (probe) {
+        if (pl->probe_used == pl->probe.size()) {
+            EvPair e{};
+            HIPCHK(c, hipEventCreate(&e.a));
+            HIPCHK(c, hipEventCreate(&e.b));
+            pl->probe.push_back(e);
+        }
+        ev = &pl->probe[pl->probe_used++];
+        HIPCHK(c, hipEventRecord(ev->a, c->stream));
+    }
+    HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
+    if (ev) HIPCHK(c, hipEventRecord(ev->b, c->stream));
+    return FDES_OK;
+}
+
+// real-space wave <-> mixed (y, kx) representation the fused loop carries between slices
+int fused_enter(fdes_plan* pl)
+{
+    PassArgs a = pass_x(pl);
+    a.in0 = pl->PSI; a.out = pl->PSIH;
+    HIPCHK(pl->ctx, lds_pass(pl->p.m1, XF_FWD, MID_NONE, XF_NONE, false, a, pl->ctx->stream));
+    return FDES_OK;
+}
+int fused_leave(fdes_plan* pl)
+{
+    PassArgs a = pass_x(pl);
+    a.in0 = pl->PSIH; a.out = pl->PSI;
+    a.scale = 1.f / (float)pl->p.m1; // PSIH = FFT_x(psi), unnormalised transforms (m1 is a power of two: exact)
+    HIPCHK(pl->ctx, lds_pass(pl->p.m1, XF_INV, MID_SCALE, XF_NONE, false, a, pl->ctx->stream));
+    return FDES_OK;
+}
+
+// incomingWave, src/multisliceSimulation.cu:563-591
+int incoming_wave(fdes_plan* pl, int k)
+{
+    fdes_ctx* c = pl->ctx;
+    const fdes_params& p = pl->p;
+    HIPCHK(c, k_fill(pl->PSI, pl->m12, 1.f, 0.f, c->stream));
+    if (p.mode == 2) {
+        HIPCHK(c, k_lens(pl->PSI, pl->kp, p.defoci[k], c->stream));
+        HIPCHK(c, fft_exec(pl,pl->PSI, true, c->stream));
+        HIPCHK(c, k_fftshift(pl->T, pl->PSI, p.m1, p.m2, c->stream));
+        HIPCHK(c, hipMemcpyAsync(pl->PSI, pl->T, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
+        RC(bandwidth_limit(pl, pl->PSI));
+        HIPCHK(c, k_normalize_to(pl->PSI, pl->m12, sqrtf((float)(p.n1 * p.n2)), pl->scal, c->stream));
+    }
+    if (p.doBeamTilt) HIPCHK(c, k_tilt_beam(pl->PSI, pl->kp, p.tiltbeam[2 * k], p.tiltbeam[2 * k + 1], 1, c->stream));
+    if (p.doBeamTilt && (p.mode == 0 || p.mode == 1)) {
+        HIPCHK(c, k_tukey(pl->PSI, pl->kp, c->stream));
+        RC(bandwidth_limit(pl, pl->PSI));
+    }
+    return FDES_OK;
+}
+
+// slice loop of one configuration up to nslices (src/crystalMaker.cu:339-344)
+int slice_loop(fdes_plan* pl, int nslices)
+{
+    BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
+    if (pl->fused) {
+        RC(fused_enter(pl));
+        for (int s = 0; s < nslices; s++) RC(fused_slice(pl, pl->xyzFP_d, g, s));
+        return fused_leave(pl);
+    }
+    for (int s = 0; s < nslices; s++) {
+        RC(phase_grating(pl, pl->xyzFP_d, g, s));
+        RC(forward_propagation(pl));
+    }
+    return FDES_OK;
+}
+
+// exit-wave post-processing + accumulation (src/crystalMaker.cu:346-366)
+int exit_wave_post(fdes_plan* pl, int k, float weight)
+{
+    fdes_ctx* c = pl->ctx;
+    const fdes_params& p = pl->p;
+    if (pl->want_ew) HIPCHK(c, k_axpy(pl->EW, pl->PSI, pl->m12, weight, c->stream));
+    if (p.mode == 0) {
+        // applyLensFunction (src/multisliceSimulation.cu:614-622) + intensityValues + Caxpy
+        HIPCHK(c, fft_exec(pl,pl->PSI, false, c->stream));
+        HIPCHK(c, k_lens(pl->PSI, pl->kp, p.defoci[k], c->stream));
+        HIPCHK(c, fft_exec(pl,pl->PSI, true, c->stream));
+        HIPCHK(c, k_intensity_axpy(pl->I, pl->PSI, pl->m12, 1.f / ((float)pl->m12), weight, c->stream));
+    } else {
+        // diffractionPattern (src/crystalMaker.cu:700-718)
+        if (p.doBeamTilt) HIPCHK(c, k_tilt_beam(pl->PSI, pl->kp, p.tiltbeam[2 * k], p.tiltbeam[2 * k + 1], -1, c->stream));
+        if (p.mode == 1) {
+            HIPCHK(c, k_mask_filter(pl->PSI, pl->kp, c->stream));
+            RC(bandwidth_limit(pl, pl->PSI));
+        }
+        HIPCHK(c, fft_exec(pl,pl->PSI, false, c->stream));
+        HIPCHK(c, k_fftshift(pl->T, pl->PSI, p.m1, p.m2, c->stream));
+        HIPCHK(c, k_intensity_axpy(pl->I, pl->T, pl->m12, sqrtf(1.f / ((float)pl->m12)), weight, c->stream));
+    }
+    return FDES_OK;
+}
+
+int check_params(fdes_ctx* ctx, const fdes_params* p, const fdes_atoms* a)
+{
+    if (!p || !a || !p->tiltspec || !p->tiltbeam || !p->defoci) { ctx->err = "null parameter / atom pointers"; return FDES_EINVAL; }
+    if (p->n3 < 1 || p->cap < p->n3 || p->n1 < 1 || p->n2 < 1 || p->dn1 < 0 || p->dn2 < 0 || p->m3 < 1) { ctx->err = "bad sizes"; return FDES_EINVAL; }
+    if (p->m1 != p->n1 + 2 * p->dn1 || p->m2 != p->n2 + 2 * p->dn2) { ctx->err = "m != n + 2*dn: call fdes_params_consistent first"; return FDES_EINVAL; }
+    if (p->m1 < 4 || p->m2 < 4) { ctx->err = "grid too small"; return FDES_EINVAL; }
+    if (p->mode < 0 || p->mode > 2) { ctx->err = "mode must be 0, 1 or 2"; return FDES_EINVAL; }
+    if (!(p->d1 > 0) || !(p->d2 > 0) || !(p->d3 > 0)) { ctx->err = "pixel sizes must be positive"; return FDES_EINVAL; }
+    if (a->nAt < 0 || (a->nAt > 0 && (!a->Z || !a->xyz || !a->dwf || !a->occ))) { ctx->err = "bad atom arrays"; return FDES_EINVAL; }
+    return FDES_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int fdes_gpu_available(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n > 0;
+}
+
+int fdes_create(fdes_ctx** out, int gpu_index)
+{
+    if (!out) return FDES_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || gpu_index < 0 || gpu_index >= n) { (void)hipGetLastError(); return FDES_EGPU; }
+    fdes_ctx* c = new fdes_ctx();
+    c->device = gpu_index;
+    if (hipSetDevice(gpu_index) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return FDES_EGPU;
+    }
+    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+    *out = c;
+    return FDES_OK;
+}
+
+int fdes_destroy(fdes_ctx* c)
+{
+    if (!c) return FDES_EINVAL;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->fft_cache) { kv.second->destroy(); delete kv.second; }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return FDES_OK;
+}
+
+const char* fdes_last_error(const fdes_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
+{
+    if (!c || !key) return FDES_EINVAL;
+    if (!std::strcmp(key, "fft")) { if (value < 0 || value > 2) return FDES_EINVAL; c->opt_fft = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
+    if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
+    if (!std::strcmp(key, "probe_stride")) { c->probe_stride = (int)value; return FDES_OK; }
+    return FDES_EINVAL;
+}
+
+int fdes_plan_destroy(fdes_plan* pl)
+{
+    if (!pl) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {pl->Z_d, pl->spec_d, pl->xyz0_d, pl->xyzTO_d, pl->xyzK_d, pl->xyzFP_d, pl->dwf_d, pl->occ_d, pl->bins.keys,
+                    pl->bins.keys_sorted, pl->bins.vals, pl->bins.order, pl->bins.seg, pl->bins.tmp, pl->D, pl->VH, pl->T, pl->PSI,
+                    pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A, pl->B, pl->C, pl->E, pl->F, pl->PSIH, pl->PT, pl->GT};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    for (auto& e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : pl->probe) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    fdes_params_release(&pl->p0);
+    delete pl;
+    return FDES_OK;
+}
+
+int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, fdes_plan** out)
+{
+    if (!c || !out) return FDES_EINVAL;
+    *out = nullptr;
+    RC(check_params(c, p_in, a));
+    HIPCHK(c, hipSetDevice(c->device));
+    fdes_plan* pl = new fdes_plan();
+    pl->ctx = c;
+    int rc = fdes_params_clone(&pl->p0, p_in);
+    if (rc) { delete pl; return rc; }
+    pl->p = pl->p0; // shares arrays
+    pl->ratio = fdes_params_sub_slices(&pl->p); // src/crystalMaker.cu:246-247
+    pl->kp = make_kp(pl->p);
+    pl->m12 = (size_t)pl->p.m1 * pl->p.m2;
+    pl->nAt = a->nAt;
+    const int nAt = a->nAt;
+    // species list in first-seen order (listOfElements, src/crystalMaker.cu:539-570)
+    std::vector<uint8_t> spec((size_t)(nAt > 0 ? nAt : 1), 0);
+    pl->nZ = 0;
+    for (int i = 0; i < nAt; i++) {
+        int f = -1;
+        for (int q = 0; q < pl->nZ; q++) if (pl->Zlist[q] == a->Z[i]) { f = q; break; }
+        if (f < 0) {
+            if (pl->nZ >= 103) { c->err = "more than 103 species"; fdes_plan_destroy(pl); return FDES_EINVAL; }
+            f = pl->nZ;
+            pl->Zlist[pl->nZ++] = a->Z[i];
+        }
+        spec[i] = (uint8_t)f;
+    }
+    if (pl->nZ == 0) { pl->nZ = 1; pl->Zlist[0] = 0; }
+    for (int q = 0; q < pl->nZ; q++) pl->kz.push_back(kirkland_params(pl->Zlist[q]));
+
+#define PLCHK(expr) do { int r_ = (expr); if (r_ != FDES_OK) { fdes_plan_destroy(pl); return r_; } } while (0)
+#define PLHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); fdes_plan_destroy(pl); return FDES_EGPU; } } while (0)
+    const size_t n3f = 3 * (size_t)nAt;
+    PLCHK(dmalloc(c, &pl->Z_d, (size_t)nAt));
+    PLCHK(dmalloc(c, &pl->spec_d, (size_t)nAt));
+    PLCHK(dmalloc(c, &pl->xyz0_d, n3f));
+    PLCHK(dmalloc(c, &pl->xyzTO_d, n3f));
+    PLCHK(dmalloc(c, &pl->xyzK_d, n3f));
+    PLCHK(dmalloc(c, &pl->xyzFP_d, n3f));
+    PLCHK(dmalloc(c, &pl->dwf_d, (size_t)nAt));
+    PLCHK(dmalloc(c, &pl->occ_d, (size_t)nAt));
+    if (nAt > 0) {
+        PLHIP(hipMemcpyAsync(pl->Z_d, a->Z, sizeof(int32_t) * nAt, hipMemcpyHostToDevice, c->stream));
+        PLHIP(hipMemcpyAsync(pl->spec_d, spec.data(), (size_t)nAt, hipMemcpyHostToDevice, c->stream));
+        PLHIP(hipMemcpyAsync(pl->xyz0_d, a->xyz, sizeof(float) * n3f, hipMemcpyHostToDevice, c->stream));
+        PLHIP(hipMemcpyAsync(pl->dwf_d, a->dwf, sizeof(float) * nAt, hipMemcpyHostToDevice, c->stream));
+        PLHIP(hipMemcpyAsync(pl->occ_d, a->occ, sizeof(float) * nAt, hipMemcpyHostToDevice, c->stream));
+        PLHIP(hipStreamSynchronize(c->stream)); // host vector `spec` goes out of scope below
+    }
+    // binning buffers sized for the larger of the sub-sliced and the original slicing
+    const int m3max = pl->p.m3 > pl->p0.m3 ? pl->p.m3 : pl->p0.m3;
+    pl->bins_cap_keys = m3max * pl->nZ;
+    PLCHK(dmalloc(c, &pl->bins.keys, (size_t)nAt));
+    PLCHK(dmalloc(c, &pl->bins.keys_sorted, (size_t)nAt));
+    PLCHK(dmalloc(c, &pl->bins.vals, (size_t)nAt));
+    PLCHK(dmalloc(c, &pl->bins.order, (size_t)nAt));
+    PLCHK(dmalloc(c, &pl->bins.seg, (size_t)pl->bins_cap_keys + 2));
+    pl->bins.tmp_bytes = geom_sort_temp_bytes(nAt);
+    PLHIP(hipMalloc(&pl->bins.tmp, pl->bins.tmp_bytes > 0 ? pl->bins.tmp_bytes : 16));
+    {   // enough blocks for an average segment, capped; the kernel strides over the rest
+        long avg = (long)nAt / (pl->p.m3 > 0 ? pl->p.m3 : 1) + 1;
+        long b = (avg * 4 + 255) / 256;
+        pl->deposit_blocks = (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+    }
+    PLCHK(dmalloc(c, &pl->D, pl->m12));
+    PLCHK(dmalloc(c, &pl->VH, pl->m12));
+    PLCHK(dmalloc(c, &pl->T, pl->m12));
+    PLCHK(dmalloc(c, &pl->PSI, pl->m12));
+    PLCHK(dmalloc(c, &pl->P, pl->m12));
+    PLCHK(dmalloc(c, &pl->I, pl->m12));
+    PLCHK(dmalloc(c, &pl->EW, pl->m12));
+    PLCHK(dmalloc(c, &pl->J, (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3));
+    PLCHK(dmalloc(c, &pl->scal, (size_t)4));
+    PLHIP(hipMemsetAsync(pl->D, 0, sizeof(float2) * pl->m12, c->stream));
+    PLHIP(hipMemsetAsync(pl->I, 0, sizeof(float2) * pl->m12, c->stream));
+    PLHIP(hipMemsetAsync(pl->EW, 0, sizeof(float2) * pl->m12, c->stream));
+    PLHIP(hipMemsetAsync(pl->J, 0, sizeof(float) * (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3, c->stream));
+    {
+        auto key = std::make_pair(pl->p.m1, pl->p.m2);
+        auto it = c->fft_cache.find(key);
+        if (it == c->fft_cache.end()) {
+            std::string ferr;
+            Fft2D* f = new Fft2D();
+            if (f->create(pl->p.m1, pl->p.m2, c->opt_fft, c->stream, &ferr) != 0) {
+                f->destroy();
+                delete f;
+                c->err = "FFT plan: " + ferr;
+                fdes_plan_destroy(pl);
+                return FDES_EGPU;
+            }
+            it = c->fft_cache.emplace(key, f).first;
+        }
+        pl->fft = it->second;
+    }
+    PLHIP(k_build_propagator(pl->P, pl->kp, 0, c->stream));
+    pl->fused = pl->fft->backend == 2;
+    if (pl->fused) {
+        PLCHK(dmalloc(c, &pl->A, pl->m12 * (size_t)pl->nZ));
+        PLCHK(dmalloc(c, &pl->B, pl->m12));
+        PLCHK(dmalloc(c, &pl->C, pl->m12));
+        PLCHK(dmalloc(c, &pl->E, pl->m12));
+        PLCHK(dmalloc(c, &pl->F, pl->m12));
+        PLCHK(dmalloc(c, &pl->PSIH, pl->m12));
+        PLCHK(dmalloc(c, &pl->PT, pl->m12));
+        PLCHK(dmalloc(c, &pl->GT, pl->m12 * (size_t)pl->nZ));
+        PLHIP(k_build_propagator(pl->PT, pl->kp, 1, c->stream));
+        for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 1, c->stream));
+    }
+    // tilt offset (src/crystalMaker.cu:282-283)
+    PLHIP(hipMemcpyAsync(pl->xyzTO_d, pl->xyz0_d, sizeof(float) * n3f, hipMemcpyDeviceToDevice, c->stream));
+    PLCHK(tilt_coordinates(pl, pl->xyzTO_d, pl->p.tilt_offset_x, pl->p.tilt_offset_y, pl->p.tilt_offset_z));
+    PLHIP(hipStreamSynchronize(c->stream));
+#undef PLCHK
+#undef PLHIP
+    *out = pl;
+    return FDES_OK;
+}
+
+int fdes_plan_begin_measurement(fdes_plan* pl, int k)
+{
+    if (!pl || k < 0 || k >= pl->p.n3) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, k_fill(pl->I, pl->m12, 0.f, 0.f, c->stream));
+    if (pl->want_ew) HIPCHK(c, k_fill(pl->EW, pl->m12, 0.f, 0.f, c->stream));
+    return ensure_tilt(pl, k);
+}
+
+int fdes_plan_run_config(fdes_plan* pl, int k, int j, float weight)
+{
+    if (!pl || k < 0 || k >= pl->p.n3 || j < 0) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    RC(incoming_wave(pl, k));
+    RC(config_atoms(pl, k, j));
+    if (pl->ev_used == pl->evs.size()) {
+        EvPair e{};
+        HIPCHK(c, hipEventCreate(&e.a));
+        HIPCHK(c, hipEventCreate(&e.b));
+        pl->evs.push_back(e);
+    }
+    EvPair& ev = pl->evs[pl->ev_used++];
+    ev.slices = pl->p.m3;
+    HIPCHK(c, hipEventRecord(ev.a, c->stream));
+    RC(slice_loop(pl, pl->p.m3));
+    HIPCHK(c, hipEventRecord(ev.b, c->stream));
+    pl->slices_done += pl->p.m3;
+    return exit_wave_post(pl, k, weight);
+}
+
+int fdes_plan_end_measurement(fdes_plan* pl, int k)
+{
+    // addNoiseAndMtf, src/crystalMaker.cu:579-613
+    if (!pl || k < 0 || k >= pl->p.n3) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    const fdes_params& p = pl->p;
+    HIPCHK(c, hipSetDevice(c->device));
+    const float alpha = 1.f / ((float)(p.m1 * p.m2));
+    HIPCHK(c, fft_exec(pl,pl->I, false, c->stream));
+    if (fabsf(p.illangle) > FLT_EPSILON) {
+        if (p.mode == 0) HIPCHK(c, k_spatial_incoherence(pl->I, pl->kp, p.defoci[k], 0, c->stream));
+        if (p.mode == 1 || p.mode == 2) HIPCHK(c, k_spatial_incoherence(pl->I, pl->kp, p.defoci[k], 1, c->stream));
+    }
+    if (p.pD > FLT_EPSILON) {
+        HIPCHK(c, k_scale(pl->I, pl->m12, alpha, c->stream));
+        HIPCHK(c, fft_exec(pl,pl->I, true, c->stream));
+        HIPCHK(c, k_noise(pl->I, pl->m12, p.pD, (uint32_t)(1 + p.n3), k, c->stream)); // seed 1 + n3, :295
+        HIPCHK(c, fft_exec(pl,pl->I, false, c->stream));
+    }
+    HIPCHK(c, k_mtf(pl->I, pl->kp, alpha, c->stream));
+    HIPCHK(c, fft_exec(pl,pl->I, true, c->stream));
+    HIPCHK(c, k_crop(pl->J + (size_t)k * p.n1 * p.n2, pl->I, pl->kp, c->stream));
+    return FDES_OK;
+}
+
+int fdes_plan_intensity_ptr(fdes_plan* pl, void** dev_ptr, size_t* bytes)
+{
+    if (!pl || !dev_ptr) return FDES_EINVAL;
+    *dev_ptr = pl->I;
+    if (bytes) *bytes = sizeof(float2) * pl->m12;
+    return FDES_OK;
+}
+
+int fdes_plan_copy_intensity(fdes_plan* pl, void* dev_buf, int to_plan)
+{
+    if (!pl || !dev_buf) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (to_plan) HIPCHK(c, hipMemcpyAsync(pl->I, dev_buf, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
+    else HIPCHK(c, hipMemcpyAsync(dev_buf, pl->I, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDES_OK;
+}
+
+int fdes_plan_images_ptr(fdes_plan* pl, void** dev_ptr, size_t* bytes)
+{
+    if (!pl || !dev_ptr) return FDES_EINVAL;
+    *dev_ptr = pl->J;
+    if (bytes) *bytes = sizeof(float) * (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3;
+    return FDES_OK;
+}
+
+int fdes_plan_sync(fdes_plan* pl)
+{
+    if (!pl) return FDES_EINVAL;
+    HIPCHK(pl->ctx, hipSetDevice(pl->ctx->device));
+    HIPCHK(pl->ctx, hipStreamSynchronize(pl->ctx->stream));
+    return FDES_OK;
+}
+
+int fdes_plan_get_images(fdes_plan* pl, float* image)
+{
+    if (!pl || !image) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(image, pl->J, sizeof(float) * (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDES_OK;
+}
+
+int fdes_plan_fft_backend(const fdes_plan* pl) { return pl ? pl->fft->backend : FDES_EINVAL; }
+int fdes_plan_num_slices(const fdes_plan* pl) { return pl ? pl->p.m3 : FDES_EINVAL; }
+int64_t fdes_plan_slices_done(const fdes_plan* pl) { return pl ? pl->slices_done : 0; }
+
+int fdes_plan_slice_loop_ms(fdes_plan* pl, double* total_ms, int64_t* slices)
+{
+    if (!pl) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double t = 0;
+    int64_t n = 0;
+    for (size_t i = 0; i < pl->ev_used; i++) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, pl->evs[i].a, pl->evs[i].b));
+        t += ms;
+        n += pl->evs[i].slices;
+    }
+    pl->ev_used = 0;
+    if (total_ms) *total_ms = t;
+    if (slices) *slices = n;
+    return FDES_OK;
+}
+
+int fdes_plan_probe_ms(fdes_plan* pl, double* total_ms, int64_t* launches)
+{
+    if (!pl) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double t = 0;
+    for (size_t i = 0; i < pl->probe_used; i++) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, pl->probe[i].a, pl->probe[i].b));
+        t += ms;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = (int64_t)pl->probe_used;
+    pl->probe_used = 0;
+    return FDES_OK;
+}
+
+// ------------------------------- stage taps (parity tests) -------------------------------------
+
+int fdes_plan_tap_coords(fdes_plan* pl, int k, int j, float* xyz)
+{
+    if (!pl || !xyz || k >= pl->p.n3) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    const float* src = pl->xyzTO_d;
+    if (k >= 0) {
+        RC(ensure_tilt(pl, k));
+        src = pl->xyzK_d;
+        if (j >= 0) { RC(config_atoms(pl, k, j)); src = pl->xyzFP_d; }
+    }
+    HIPCHK(c, hipMemcpyAsync(xyz, src, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDES_OK;
+}
+
+int fdes_plan_tap_potential(fdes_plan* pl, int k, int j, int s, float* V)
+{
+    if (!pl || !V || k < 0 || k >= pl->p.n3 || s < 0 || s >= pl->p.m3) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    RC(config_atoms(pl, k, j < 0 ? 0 : j));
+    BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
+    if (pl->fused) {
+        RC(fused_potential_spectrum(pl, pl->xyzFP_d, g, s));
+        PassArgs a = pass_x(pl);
+        a.in0 = pl->B; a.out = pl->VH;
+        HIPCHK(c, lds_pass(pl->p.m1, XF_INV, MID_NONE, XF_NONE, false, a, c->stream));
+    } else {
+        RC(phase_grating(pl, pl->xyzFP_d, g, s));
+    }
+    HIPCHK(c, hipMemcpyAsync(V, pl->VH, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDES_OK;
+}
+
+int fdes_plan_tap_wave(fdes_plan* pl, int k, int j, int nslices, float* psi)
+{
+    if (!pl || !psi || k < 0 || k >= pl->p.n3 || nslices < 0 || nslices > pl->p.m3) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    RC(incoming_wave(pl, k));
+    RC(config_atoms(pl, k, j < 0 ? 0 : j));
+    RC(slice_loop(pl, nslices));
+    HIPCHK(c, hipMemcpyAsync(psi, pl->PSI, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDES_OK;
+}
+
+int fdes_plan_tap_propagator(fdes_plan* pl, float* P)
+{
+    if (!pl || !P) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(P, pl->P, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDES_OK;
+}
+
+int fdes_plan_propagate_dev(fdes_plan* pl, void* psi_dev, const void* t_dev, int batch, int t_per_wave)
+{
+    if (!pl || !psi_dev || !t_dev || batch < 1) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int b = 0; b < batch; b++) {
+        float2* psi = (float2*)psi_dev + (size_t)b * pl->m12;
+        const float2* t = (const float2*)t_dev + (t_per_wave ? (size_t)b * pl->m12 : 0);
+        HIPCHK(c, k_mul(psi, t, psi, pl->m12, c->stream));
+        HIPCHK(c, fft_exec(pl,psi, false, c->stream));
+        HIPCHK(c, k_mul(psi, psi, pl->P, pl->m12, c->stream));
+        HIPCHK(c, fft_exec(pl,psi, true, c->stream));
+    }
+    return FDES_OK;
+}
+
+// 2-D FFT of a host grid through the engine's FFT back-end (test hook for the FFT itself).
+int fdes_fft2d_host(fdes_ctx* c, float* data, int m1, int m2, int inverse, int backend)
+{
+    if (!c || !data || m1 < 2 || m2 < 2) return FDES_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    Fft2D f;
+    std::string ferr;
+    if (f.create(m1, m2, backend, c->stream, &ferr) != 0) { f.destroy(); c->err = "FFT plan: " + ferr; return FDES_EGPU; }
+    float2* d = nullptr;
+    const size_t bytes = sizeof(float2) * (size_t)m1 * m2;
+    hipError_t e = hipMalloc((void**)&d, bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = f.exec(d, inverse != 0, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d) (void)hipFree(d);
+    const int used = f.backend;
+    f.destroy();
+    if (e != hipSuccess) { c->err = std::string("fft2d_host: ") + hipGetErrorString(e); return FDES_EGPU; }
+    return used; // 1 = rocFFT, 2 = LDS kernels
+}
+
+// ------------------------------- buildMeasurements ---------------------------------------------
+
+int fdes_build_measurements(fdes_ctx* c, const fdes_params* p, const fdes_atoms* a, float* image, float* potential, float* exitwave)
+{
+    if (!c || !image) return FDES_EINVAL;
+    fdes_plan* pl = nullptr;
+    RC(fdes_plan_create(c, p, a, &pl));
+    pl->want_ew = exitwave != nullptr;
+    const int count = pl->p.frPh > 0 ? pl->p.frPh : 1;
+    const float alpha = 1.f / ((float)count); // src/crystalMaker.cu:302-304
+    int rc = FDES_OK;
+    for (int k = 0; k < pl->p.n3 && rc == FDES_OK; k++) {
+        rc = fdes_plan_begin_measurement(pl, k);
+        for (int j = 0; j < count && rc == FDES_OK; j++) rc = fdes_plan_run_config(pl, k, j, alpha);
+        if (rc == FDES_OK && exitwave) {
+            hipError_t e = hipMemcpyAsync(exitwave + 2 * pl->m12 * (size_t)k, pl->EW, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = FDES_EGPU; }
+        }
+        if (rc == FDES_OK) rc = fdes_plan_end_measurement(pl, k);
+    }
+    if (rc == FDES_OK) rc = fdes_plan_get_images(pl, image);
+    if (rc == FDES_OK && potential) {
+        // src/crystalMaker.cu:381-397: tilt-offset-only, un-jittered potential per ORIGINAL slice
+        // (setSubSlices(1/ratio)).  Always computed (the reference leaves it uninitialised when
+        // ratio == 1, frPh == 0 and the last specimen tilt is zero).
+        const float inv = 1.f / (float)pl->ratio;
+        BinGeom g{pl->p.m1, pl->p.m2, (int)(((float)pl->p.m3) * inv), pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3 / inv};
+        hipError_t e = geom_bin_atoms(pl->xyzTO_d, pl->spec_d, pl->nAt, g, pl->bins, c->stream);
+        if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = FDES_EGPU; }
+        for (int s = 0; s < g.m3 && rc == FDES_OK; s++) {
+            rc = phase_grating(pl, pl->xyzTO_d, g, s);
+            if (rc == FDES_OK) {
+                e = hipMemcpyAsync(potential + 2 * pl->m12 * (size_t)s, pl->VH, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = FDES_EGPU; }
+            }
+        }
+    }
+    fdes_plan_destroy(pl);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,96 @@
+// fft.hip — FFT back-ends of the engine (see fft.h).
+#include "fft.h"
+
+#include <rocfft/rocfft.h>
+
+#include <vector>
+
+#include "fft_lds.h"
+
+namespace fdes {
+
+bool Fft2D::lds_supported(int m1, int m2)
+{
+    if (!lds_fft_supported_len(m1) || !lds_fft_supported_len(m2)) return false;
+    return (m2 % lds_fft_rows_per_block(m1) == 0) && (m1 % lds_fft_rows_per_block(m2) == 0);
+}
+
+static int upload_twiddles(int n, float2** tw0, float2** tw1, std::string* err)
+{
+    const int T = n / 16, P = T / 16 > 0 ? T / 16 : 1;
+    std::vector<float> h0(2 * 16 * (size_t)T), h1(2 * 16 * (size_t)P);
+    lds_fft_twiddles(n, h0.data(), h1.data());
+    if (hipMalloc((void**)tw0, h0.size() * sizeof(float)) != hipSuccess || hipMalloc((void**)tw1, h1.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(*tw0, h0.data(), h0.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(*tw1, h1.data(), h1.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        if (err) *err = "twiddle upload failed";
+        return -1;
+    }
+    return 0;
+}
+
+int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err)
+{
+    m1 = m1_;
+    m2 = m2_;
+    const bool lds_ok = lds_supported(m1, m2);
+    if (opt == 2 && !lds_ok) { if (err) *err = "hand-written FFT needs power-of-two grids of 256..4096 points"; return -1; }
+    backend = (opt == 1 || !lds_ok) ? 1 : 2;
+    if (backend == 2) {
+        if (upload_twiddles(m1, &tw0x, &tw1x, err)) return -1;
+        if (upload_twiddles(m2, &tw0y, &tw1y, err)) return -1;
+        if (hipMalloc((void**)&scratch, sizeof(float2) * (size_t)m1 * m2) != hipSuccess) { if (err) *err = "scratch allocation failed"; return -1; }
+        return 0;
+    }
+    const size_t lengths[2] = {(size_t)m1, (size_t)m2}; // rocFFT: lengths[0] is the fastest dimension
+    rocfft_status s;
+    s = rocfft_plan_create(&fwd, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_single, 2, lengths, 1, nullptr);
+    if (s != rocfft_status_success) { if (err) *err = "rocfft_plan_create(forward) failed: " + std::to_string((int)s); return -1; }
+    s = rocfft_plan_create(&inv, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_single, 2, lengths, 1, nullptr);
+    if (s != rocfft_status_success) { if (err) *err = "rocfft_plan_create(inverse) failed: " + std::to_string((int)s); return -1; }
+    size_t w1 = 0, w2 = 0;
+    rocfft_plan_get_work_buffer_size(fwd, &w1);
+    rocfft_plan_get_work_buffer_size(inv, &w2);
+    work_bytes = w1 > w2 ? w1 : w2;
+    s = rocfft_execution_info_create(&info);
+    if (s != rocfft_status_success) { if (err) *err = "rocfft_execution_info_create failed"; return -1; }
+    if (work_bytes) {
+        if (hipMalloc(&work, work_bytes) != hipSuccess) { if (err) *err = "work buffer allocation failed"; return -1; }
+        rocfft_execution_info_set_work_buffer(info, work, work_bytes);
+    }
+    rocfft_execution_info_set_stream(info, st);
+    return 0;
+}
+
+hipError_t Fft2D::exec(float2* data, bool inverse, hipStream_t st)
+{
+    if (backend == 2) {
+        // pass 1: rows along x (length m1, m2 rows) -> scratch[kx][y]; pass 2: rows along y -> data[ky][kx]
+        const int xf = inverse ? XF_INV : XF_FWD;
+        PassArgs a;
+        a.in0 = data; a.out = scratch; a.tw0 = tw0x; a.tw1 = tw1x; a.nrows = m2;
+        hipError_t e = lds_pass(m1, xf, MID_NONE, XF_NONE, true, a, st);
+        if (e != hipSuccess) return e;
+        PassArgs b;
+        b.in0 = scratch; b.out = data; b.tw0 = tw0y; b.tw1 = tw1y; b.nrows = m1;
+        return lds_pass(m2, xf, MID_NONE, XF_NONE, true, b, st);
+    }
+    void* in[1] = {data};
+    rocfft_status s = rocfft_execute(inverse ? inv : fwd, in, nullptr, info);
+    return s == rocfft_status_success ? hipSuccess : hipErrorUnknown;
+}
+
+void Fft2D::destroy()
+{
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+    if (info) rocfft_execution_info_destroy(info);
+    void* ptrs[] = {work, tw0x, tw1x, tw0y, tw1y, scratch};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    fwd = inv = nullptr;
+    info = nullptr;
+    work = nullptr;
+    tw0x = tw1x = tw0y = tw1y = scratch = nullptr;
+}
+
+} // namespace fdes

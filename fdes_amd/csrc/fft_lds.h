@@ -1,0 +1,54 @@
+// fft_lds.h — hand-written LDS row-FFT passes for power-of-two grids (gfx950).
+//
+// A "pass" streams whole rows of a 2-D complex grid through one workgroup: coalesced row loads ->
+// [row FFT] -> point-wise operation -> [row FFT] -> store, either in place order (natural) or
+// transposed (so that the next pass finds the other axis contiguous).  A 2-D FFT is two passes
+// with transposed stores; the slice loop of the multislice engine chains six such passes per slice
+// and never runs a stand-alone point-wise kernel ("Fused slice loop").
+#ifndef FDES_FFT_LDS_H_
+#define FDES_FFT_LDS_H_
+#include <hip/hip_runtime.h>
+
+namespace fdes {
+
+enum XfKind { XF_NONE = 0, XF_FWD = 1, XF_INV = 2 };
+enum MidKind {
+    MID_NONE = 0,
+    MID_ZSRC = 1,   // none, but the source rows are overwritten with zeros after loading (deposit grid)
+    MID_GTAB = 2,   // spectrum * G[row][col]                            (projected potential filter, 1 species)
+    MID_EXPIV = 3,  // v -> exp(-v.y) (cos v.x, sin v.x)               (potential2Transmission)
+    MID_MASK = 4,   // radial 2/3 band limit * scale                     (zeroHighFreq + Csscal)
+    MID_MULPSI = 5, // (row of in0) (x) (row of in1), both inverse transformed first (multiplyElementwise)
+    MID_PTAB = 6,   // spectrum (x) P[row][col]                          (multiplyElementwise with frProp)
+    MID_SCALE = 7,  // * scale
+    MID_GTABN = 8   // MID_GTAB with a species loop (nspecies > 1)
+};
+
+struct PassArgs {
+    const float2* in0 = nullptr;
+    const float2* in1 = nullptr;
+    float2* out = nullptr;
+    float2* zsrc = nullptr;      // MID_ZSRC: rows to clear (== in0)
+    const float* gtab = nullptr; // MID_GTAB: [species][row][col]
+    const float2* ptab = nullptr;
+    const float2* tw0 = nullptr; // twiddles of this row length
+    const float2* tw1 = nullptr;
+    int nrows = 0;               // rows of the input grid (= leading dimension of a transposed output)
+    int nspecies = 1;
+    size_t species_stride = 0;   // elements between species grids (in0 and gtab)
+    float scale = 1.f;
+    int mindim = 0;              // min(m1, m2) for the band limit
+};
+
+// Row lengths the kernels are instantiated for.
+bool lds_fft_supported_len(int n);
+// rows per workgroup for row length n
+int lds_fft_rows_per_block(int n);
+// fills host arrays (float2 as 2 floats) with the twiddle tables of length n: tw0[16*T], tw1[T]
+void lds_fft_twiddles(int n, float* tw0, float* tw1);
+
+// Launch one pass over all rows. n = row length, kinds select the template instantiation.
+hipError_t lds_pass(int n, int pre, int mid, int post, bool store_transposed, const PassArgs& a, hipStream_t st);
+
+} // namespace fdes
+#endif

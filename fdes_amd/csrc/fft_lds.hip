@@ -1,0 +1,456 @@
+// fft_lds.hip — LDS row-FFT pass kernels for gfx950 (see fft_lds.h).
+//
+// Row FFT of length N = 16 * 16 * R3 (R3 = N/256 in {1,2,4,8,16}), T = N/16 threads per row, each
+// thread holding 16 complex values in registers (Stockham autosort, decimation in frequency):
+//   stage 0: thread t loads x[t + T*l], radix-16 butterfly, twiddle W_N^(t*k), LDS write at 16t+k
+//   stage 1: reads x[t + T*l] again (autosort keeps the read pattern), radix-16, twiddle
+//            W_(N/16)^(p*k) (p = t/16), LDS write at q + 256p + 16k (q = t%16)
+//   stage 2: reads x[t + T*l], 16/R3 radix-R3 butterflies over registers {i + (16/R3) j}: no
+//            twiddle, and the outputs are thread-local and in natural order: register l of thread
+//            t is X[t + T*l] - exactly the input pattern of stage 0, so two transforms chain
+//            through registers (FFT -> point-wise -> inverse FFT without touching LDS in between).
+// LDS rows are padded by one element per 16 (index i -> i + i/16): the stride-16 writes of stage 0
+// become stride 17 (conflict-free for ds_write_b64's 16-lane groups), reads stay contiguous.
+// A workgroup is 512 threads and R = 16384/N rows (8 rows at N = 2048), every thread carrying two
+// rows (shared twiddles, twice the work per barrier); LDS = 136 KiB -> one workgroup per CU,
+// 2 waves per SIMD with a 256-VGPR budget (the 1024-thread form spills at 128 VGPRs).  The transposed store stages the R x N tile through the
+// same LDS (swizzled so both the row-wise write and the column-wise read are conflict-free) and
+// writes R contiguous elements per output row; blockIdx is remapped so that workgroups sharing an
+// XCD (blockIdx % 8 equal) own consecutive row groups and their partial 128-byte lines merge in
+// that XCD's L2.
+#include "fft_lds.h"
+
+#include <cmath>
+
+namespace fdes {
+
+namespace {
+
+constexpr float C1 = 0.923879532511286756f; // cos(pi/8)
+constexpr float S1 = 0.382683432365089772f; // sin(pi/8)
+constexpr float C2 = 0.707106781186547524f; // cos(pi/4)
+
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a * conj(b)
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+// multiply by the forward twiddle w (INV = false) or its conjugate (INV = true)
+template <bool INV> __device__ __forceinline__ float2 twmul(float2 a, float2 w) { return INV ? cmulc(a, w) : cmul(a, w); }
+// multiply by -i (forward) / +i (inverse)
+template <bool INV> __device__ __forceinline__ float2 mul_mi(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+// 3-multiply complex product of the reference (src/complexMath.cu:44-62): f0 = (a, b), f1 = (c, d)
+__device__ __forceinline__ float2 cmul3(float2 f0, float2 f1)
+{
+    const float a = f0.x, b = f0.y;
+    float c = f1.x, d = f1.y;
+    const float k = a * (c + d);
+    d *= a + b;
+    c *= b - a;
+    return make_float2(k - d, k + c);
+}
+
+template <bool INV> __device__ __forceinline__ void r2(float2& x0, float2& x1)
+{
+    const float2 t = x0 - x1;
+    x0 = x0 + x1;
+    x1 = t;
+}
+
+template <bool INV> __device__ __forceinline__ void r4(float2& x0, float2& x1, float2& x2, float2& x3)
+{
+    const float2 t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = mul_mi<INV>(x1 - x3);
+    x0 = t0 + t2;
+    x1 = t1 + t3;
+    x2 = t0 - t2;
+    x3 = t1 - t3;
+}
+
+// in-place 8-point DFT, natural order in and out
+template <bool INV> __device__ __forceinline__ void r8(float2& a0, float2& a1, float2& a2, float2& a3, float2& a4, float2& a5, float2& a6,
+                                                       float2& a7)
+{
+    // j = 2 j1 + j0: radix-4 over j1 for j0 = 0 (a0,a2,a4,a6) and j0 = 1 (a1,a3,a5,a7)
+    r4<INV>(a0, a2, a4, a6); // c[0][k0] in a0,a2,a4,a6
+    r4<INV>(a1, a3, a5, a7); // c[1][k0] in a1,a3,a5,a7
+    // twiddle c[1][k0] *= w8^k0
+    a3 = twmul<INV>(a3, make_float2(C2, -C2));
+    a5 = mul_mi<INV>(a5);
+    a7 = twmul<INV>(a7, make_float2(-C2, -C2));
+    // b[k0 + 4 k1] = c[0][k0] +- c[1][k0]
+    float2 b0 = a0 + a1, b4 = a0 - a1, b1 = a2 + a3, b5 = a2 - a3, b2 = a4 + a5, b6 = a4 - a5, b3 = a6 + a7, b7 = a6 - a7;
+    a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+}
+
+// in-place 16-point DFT, natural order in and out
+template <bool INV> __device__ __forceinline__ void r16(float2 (&a)[16])
+{
+    // j = 4 j1 + j0: radix-4 over j1 -> c[j0][k0] left at a[4 k0 + j0]
+#pragma unroll
+    for (int j0 = 0; j0 < 4; j0++) r4<INV>(a[j0], a[4 + j0], a[8 + j0], a[12 + j0]);
+    // twiddles w16^(j0 k0)
+    a[4 + 1] = twmul<INV>(a[4 + 1], make_float2(C1, -S1));   // m = 1
+    a[4 + 2] = twmul<INV>(a[4 + 2], make_float2(C2, -C2));   // m = 2
+    a[4 + 3] = twmul<INV>(a[4 + 3], make_float2(S1, -C1));   // m = 3
+    a[8 + 1] = twmul<INV>(a[8 + 1], make_float2(C2, -C2));   // m = 2
+    a[8 + 2] = mul_mi<INV>(a[8 + 2]);                        // m = 4
+    a[8 + 3] = twmul<INV>(a[8 + 3], make_float2(-C2, -C2));  // m = 6
+    a[12 + 1] = twmul<INV>(a[12 + 1], make_float2(S1, -C1)); // m = 3
+    a[12 + 2] = twmul<INV>(a[12 + 2], make_float2(-C2, -C2)); // m = 6
+    a[12 + 3] = twmul<INV>(a[12 + 3], make_float2(-C1, S1)); // m = 9
+    // radix-4 over j0 for each k0: b[k0 + 4 k1] left at a[4 k0 + k1]
+#pragma unroll
+    for (int k0 = 0; k0 < 4; k0++) r4<INV>(a[4 * k0], a[4 * k0 + 1], a[4 * k0 + 2], a[4 * k0 + 3]);
+    // 4x4 transpose of the register indices -> natural order
+    float2 t;
+#define SWP(i, j) t = a[i]; a[i] = a[j]; a[j] = t;
+    SWP(1, 4) SWP(2, 8) SWP(3, 12) SWP(6, 9) SWP(7, 13) SWP(11, 14)
+#undef SWP
+}
+
+// sin/cos with a two-constant Cody-Waite reduction (|x| < ~1e4: projected-potential phases are a few
+// radians) and degree-9/8 polynomials on [-pi/4, pi/4]; abs. error < 2e-7.  The library sincosf
+// carries a Payne-Hanek slow path whose register footprint made the fused pass spill.
+__device__ __forceinline__ void sincos_cw(float x, float& s, float& c)
+{
+    const float kf = rintf(x * 0.636619772f);
+    const int k = (int)kf;
+    float r = fmaf(-kf, 1.57079601e+00f, x);
+    r = fmaf(-kf, 3.13916473e-07f, r);
+    r = fmaf(-kf, 5.39030253e-15f, r);
+    const float r2 = r * r;
+    float sp = 2.75573192e-6f;
+    sp = fmaf(sp, r2, -1.98412701e-4f);
+    sp = fmaf(sp, r2, 8.33333377e-3f);
+    sp = fmaf(sp, r2, -1.66666672e-1f);
+    const float sn = fmaf(r * r2, sp, r);
+    float cp = 2.48015876e-5f;
+    cp = fmaf(cp, r2, -1.38888892e-3f);
+    cp = fmaf(cp, r2, 4.16666679e-2f);
+    cp = fmaf(cp, r2, -0.5f);
+    const float cs = fmaf(cp, r2, 1.0f);
+    const float s_ = (k & 1) ? cs : sn;
+    const float c_ = (k & 1) ? sn : cs;
+    s = (k & 2) ? -s_ : s_;
+    c = ((k + 1) & 2) ? -c_ : c_;
+}
+
+__device__ __forceinline__ int padi(int i) { return i + (i >> 4); }
+__device__ __forceinline__ int iwc(int i, int m) { return (i > m / 2) ? i - m : i; } // iwCoordIp
+
+constexpr int NR = 2;        // rows per thread (twiddles are shared between them)
+constexpr int WG = 512;      // threads per workgroup: 8 waves = 2 per SIMD -> 256 VGPRs per lane
+
+template <int N> struct Geo {
+    static constexpr int T = N / 16;                 // threads per row
+    static constexpr int R = 16384 / N;              // rows per workgroup
+    static constexpr int RH = R / NR;                // rows per "half": thread (r, t) owns rows r and r + RH
+    static constexpr int R3 = N / 256;               // radix of the last stage
+    static constexpr int G = (R3 >= 1) ? 16 / R3 : 16;
+    static constexpr int LDROW = N + N / 16;         // padded row length in float2
+    static constexpr int SH = (R >= 16) ? 0 : ((R == 8) ? 1 : 2); // transposed-tile swizzle shift
+};
+
+// NR row FFTs at once, data in a[h][16] (a[h][l] = x_h[t + T l] on entry, X_h[t + T l] on exit).
+template <int N, bool INV, bool WAR0>
+__device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict__ lds, const int r, const int t,
+                                        const float2* __restrict__ tw0, const float2* __restrict__ tw1)
+{
+    using G_ = Geo<N>;
+    constexpr int T = G_::T;
+    // ---- stage 0
+#pragma unroll
+    for (int h = 0; h < NR; h++) r16<INV>(a[h]);
+#pragma unroll
+    for (int k = 1; k < 16; k++) {
+        const float2 w = tw0[k * T + t];
+#pragma unroll
+        for (int h = 0; h < NR; h++) a[h][k] = twmul<INV>(a[h][k], w);
+    }
+    if (WAR0) __syncthreads();
+#pragma unroll
+    for (int h = 0; h < NR; h++) {
+        float2* row = lds + (r + h * G_::RH) * G_::LDROW;
+#pragma unroll
+        for (int k = 0; k < 16; k++) row[padi(16 * t + k)] = a[h][k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < NR; h++) {
+        const float2* row = lds + (r + h * G_::RH) * G_::LDROW;
+#pragma unroll
+        for (int l = 0; l < 16; l++) a[h][l] = row[padi(t + T * l)];
+    }
+    // ---- stage 1
+#pragma unroll
+    for (int h = 0; h < NR; h++) r16<INV>(a[h]);
+    if constexpr (G_::R3 > 1) {
+        const int q = t & 15, p = t >> 4;
+#pragma unroll
+        for (int k = 1; k < 16; k++) {
+            const float2 w = tw1[k * (T / 16) + p];
+#pragma unroll
+            for (int h = 0; h < NR; h++) a[h][k] = twmul<INV>(a[h][k], w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < NR; h++) {
+            float2* row = lds + (r + h * G_::RH) * G_::LDROW;
+#pragma unroll
+            for (int k = 0; k < 16; k++) row[padi(q + 256 * p + 16 * k)] = a[h][k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < NR; h++) {
+            const float2* row = lds + (r + h * G_::RH) * G_::LDROW;
+#pragma unroll
+            for (int l = 0; l < 16; l++) a[h][l] = row[padi(t + T * l)];
+        }
+        // ---- stage 2: G butterflies of radix R3 over registers {i + G j}
+#pragma unroll
+        for (int h = 0; h < NR; h++) {
+            if constexpr (G_::R3 == 2) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) r2<INV>(a[h][i], a[h][i + 8]);
+            } else if constexpr (G_::R3 == 4) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) r4<INV>(a[h][i], a[h][i + 4], a[h][i + 8], a[h][i + 12]);
+            } else if constexpr (G_::R3 == 8) {
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+                    r8<INV>(a[h][i], a[h][i + 2], a[h][i + 4], a[h][i + 6], a[h][i + 8], a[h][i + 10], a[h][i + 12], a[h][i + 14]);
+            } else {
+                r16<INV>(a[h]);
+            }
+        }
+    }
+}
+
+template <int N, int XF, bool WAR0>
+__device__ __forceinline__ void xform(float2 (&a)[NR][16], float2* lds, int r, int t, const float2* tw0, const float2* tw1)
+{
+    if constexpr (XF == XF_FWD) row_fft<N, false, WAR0>(a, lds, r, t, tw0, tw1);
+    if constexpr (XF == XF_INV) row_fft<N, true, WAR0>(a, lds, r, t, tw0, tw1);
+}
+
+template <int N, int PRE, int MID, int POST, bool STORE_T>
+__global__ __launch_bounds__(WG) void k_pass(PassArgs A)
+{
+    using G_ = Geo<N>;
+    constexpr int T = G_::T, R = G_::R, RH = G_::RH;
+    extern __shared__ float2 lds[];
+    const int tid = threadIdx.x;
+    const int r = tid / T, t = tid % T;
+    // XCD-aware remap: blocks with equal blockIdx % 8 share an XCD; give them consecutive row groups
+    int bg = blockIdx.x;
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bg = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+    const int row0 = bg * R;
+    const float2* __restrict__ tw0 = A.tw0;
+    const float2* __restrict__ tw1 = A.tw1;
+    size_t rbase[NR];
+    int grow[NR];
+#pragma unroll
+    for (int h = 0; h < NR; h++) {
+        grow[h] = row0 + r + h * RH;
+        rbase[h] = (size_t)grow[h] * N;
+    }
+
+    float2 a[NR][16];
+    if constexpr (MID == MID_GTABN) {
+        // sum over species in Fourier space, then one inverse transform (phaseGrating's species loop)
+        float2 acc[NR][16];
+#pragma unroll
+        for (int h = 0; h < NR; h++)
+#pragma unroll
+            for (int l = 0; l < 16; l++) acc[h][l] = make_float2(0.f, 0.f);
+        for (int z = 0; z < A.nspecies; z++) {
+            const size_t zo = (size_t)z * A.species_stride;
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) a[h][l] = A.in0[zo + rbase[h] + t + T * l];
+            xform<N, PRE, true>(a, lds, r, t, tw0, tw1);
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) {
+                    const float gv = A.gtab[zo + rbase[h] + t + T * l];
+                    acc[h][l].x += a[h][l].x * gv;
+                    acc[h][l].y += a[h][l].y * gv;
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < NR; h++)
+#pragma unroll
+            for (int l = 0; l < 16; l++) a[h][l] = acc[h][l];
+    } else {
+#pragma unroll
+        for (int h = 0; h < NR; h++)
+#pragma unroll
+            for (int l = 0; l < 16; l++) a[h][l] = A.in0[rbase[h] + t + T * l];
+        if constexpr (MID == MID_ZSRC) {
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) A.zsrc[rbase[h] + t + T * l] = make_float2(0.f, 0.f);
+        }
+        xform<N, PRE, false>(a, lds, r, t, tw0, tw1);
+        if constexpr (MID == MID_EXPIV) {
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) {
+                    const float e = __expf(-a[h][l].y);
+                    float sn, cs;
+                    sincos_cw(a[h][l].x, sn, cs);
+                    a[h][l] = make_float2(e * cs, e * sn);
+                }
+        } else if constexpr (MID == MID_MASK) {
+            const float md = (float)A.mindim;
+#pragma unroll
+            for (int h = 0; h < NR; h++) {
+                const int i2 = iwc(grow[h], A.nrows);
+#pragma unroll
+                for (int l = 0; l < 16; l++) {
+                    const int i1 = iwc(t + T * l, N);
+                    const bool outside = ((float)(i1 * i1 + i2 * i2) * 9.f / (md * md)) > 1.f;
+                    a[h][l] = outside ? make_float2(0.f, 0.f) : make_float2(a[h][l].x * A.scale, a[h][l].y * A.scale);
+                }
+            }
+        } else if constexpr (MID == MID_SCALE) {
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) a[h][l] = make_float2(a[h][l].x * A.scale, a[h][l].y * A.scale);
+        } else if constexpr (MID == MID_GTAB) {
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) {
+                    const float gv = A.gtab[rbase[h] + t + T * l];
+                    a[h][l] = make_float2(a[h][l].x * gv, a[h][l].y * gv);
+                }
+        } else if constexpr (MID == MID_PTAB) {
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], A.ptab[rbase[h] + t + T * l]);
+        } else if constexpr (MID == MID_MULPSI) {
+            float2 b[NR][16];
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) b[h][l] = A.in1[rbase[h] + t + T * l];
+            xform<N, PRE, true>(b, lds, r, t, tw0, tw1);
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], b[h][l]); // f0 = t, f1 = psi
+        }
+    }
+    xform<N, POST, (PRE != XF_NONE)>(a, lds, r, t, tw0, tw1);
+
+    if constexpr (!STORE_T) {
+#pragma unroll
+        for (int h = 0; h < NR; h++)
+#pragma unroll
+            for (int l = 0; l < 16; l++) A.out[rbase[h] + t + T * l] = a[h][l];
+    } else {
+        // stage the R x N tile as [c][r] (swizzled) and write R contiguous elements per output row
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < NR; h++) {
+            const int rr = r + h * RH;
+#pragma unroll
+            for (int l = 0; l < 16; l++) {
+                const int c = t + T * l;
+                lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))] = a[h][l];
+            }
+        }
+        __syncthreads();
+        float2* __restrict__ dst = A.out;
+        const int ld = A.nrows; // transposed grid: N rows of length nrows
+#pragma unroll
+        for (int it = 0; it < 16384 / WG; it++) {
+            const int e = it * WG + tid;
+            const int rr = e & (R - 1), c = e / R;
+            dst[(size_t)c * ld + row0 + rr] = lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))];
+        }
+    }
+}
+
+template <int N, int PRE, int MID, int POST, bool ST> hipError_t launch(const PassArgs& a, hipStream_t st)
+{
+    using G_ = Geo<N>;
+    static bool attr_set = false;
+    constexpr size_t lds_bytes = sizeof(float2) * (size_t)G_::LDROW * G_::R;
+    auto kern = k_pass<N, PRE, MID, POST, ST>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (a.nrows % G_::R != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3(a.nrows / G_::R), dim3(WG), lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+template <int N> hipError_t dispatch(int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
+{
+#define CASE(P, M, Q, S) if (pre == P && mid == M && post == Q && st_t == S) return launch<N, P, M, Q, S>(a, st);
+    CASE(XF_FWD, MID_NONE, XF_NONE, false)   // real -> mixed, natural store            (start of a configuration)
+    CASE(XF_INV, MID_NONE, XF_NONE, false)   // mixed -> real, natural store            (end of a configuration)
+    CASE(XF_INV, MID_SCALE, XF_NONE, false)
+    CASE(XF_FWD, MID_NONE, XF_NONE, true)    // generic 2-D FFT passes
+    CASE(XF_INV, MID_NONE, XF_NONE, true)
+    CASE(XF_FWD, MID_SCALE, XF_NONE, true)
+    CASE(XF_INV, MID_SCALE, XF_NONE, true)
+    CASE(XF_FWD, MID_ZSRC, XF_NONE, true)    // P1: deposit grid -> x spectrum
+    CASE(XF_FWD, MID_GTAB, XF_INV, true)     // P2: y FFT * f_e/sinc, y IFFT (one species)
+    CASE(XF_FWD, MID_GTABN, XF_INV, true)    // P2: y FFT * f_e/sinc, species sum, y IFFT
+    CASE(XF_INV, MID_EXPIV, XF_FWD, true)    // P3: x IFFT, exp(iV), x FFT
+    CASE(XF_FWD, MID_MASK, XF_INV, true)     // P4: y FFT, band limit, y IFFT
+    CASE(XF_INV, MID_MULPSI, XF_FWD, true)   // P5: x IFFT of t and psi, product, x FFT
+    CASE(XF_FWD, MID_PTAB, XF_INV, true)     // P6: y FFT, * propagator, y IFFT
+#undef CASE
+    return hipErrorInvalidValue;
+}
+
+} // namespace
+
+bool lds_fft_supported_len(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
+int lds_fft_rows_per_block(int n) { return 16384 / n; }
+
+void lds_fft_twiddles(int n, float* tw0, float* tw1)
+{
+    const int T = n / 16;
+    const double w = -2.0 * 3.14159265358979323846 / (double)n;
+    for (int k = 0; k < 16; k++)
+        for (int t = 0; t < T; t++) {
+            const double a = w * (double)t * (double)k;
+            tw0[2 * (k * T + t)] = (float)std::cos(a);
+            tw0[2 * (k * T + t) + 1] = (float)std::sin(a);
+        }
+    const int P = T / 16 > 0 ? T / 16 : 1;
+    for (int k = 0; k < 16; k++)
+        for (int p = 0; p < P; p++) {
+            const double a = w * 16.0 * (double)p * (double)k;
+            tw1[2 * (k * P + p)] = (float)std::cos(a);
+            tw1[2 * (k * P + p) + 1] = (float)std::sin(a);
+        }
+}
+
+hipError_t lds_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
+{
+    switch (n) {
+    case 256: return dispatch<256>(pre, mid, post, st_t, a, st);
+    case 512: return dispatch<512>(pre, mid, post, st_t, a, st);
+    case 1024: return dispatch<1024>(pre, mid, post, st_t, a, st);
+    case 2048: return dispatch<2048>(pre, mid, post, st_t, a, st);
+    case 4096: return dispatch<4096>(pre, mid, post, st_t, a, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace fdes

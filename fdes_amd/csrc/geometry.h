@@ -1,0 +1,29 @@
+// geometry.h — host-callable launchers of geometry.hip.
+#ifndef FDES_GEOMETRY_H_
+#define FDES_GEOMETRY_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fdes {
+
+struct BinGeom { // what squareAtoms_d reads from params_t (src/crystalMaker.cu:81-87)
+    int m1, m2, m3, nZ;
+    float d1, d2, d3;
+};
+
+struct AtomBins { // device buffers of the per-configuration (slice, species) binning
+    uint32_t *keys = nullptr, *keys_sorted = nullptr, *vals = nullptr, *order = nullptr;
+    int* seg = nullptr; // [m3*nZ + 2]
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+};
+
+hipError_t geom_srot(float* xyz, int nAt, int ax, int ay, float c, float s, hipStream_t st);
+hipError_t geom_jitter(float* out, const float* in, const float* dwf, int nAt, uint32_t seed, int k, int j, hipStream_t st);
+size_t geom_sort_temp_bytes(int nAt);
+hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, int nAt, const BinGeom& g, AtomBins& b, hipStream_t st);
+hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key, const BinGeom& g,
+                        float imPot, int blocks, hipStream_t st);
+
+} // namespace fdes
+#endif

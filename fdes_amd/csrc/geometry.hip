@@ -1,0 +1,165 @@
+// geometry.hip — atom geometry on the GPU: tilts, frozen-phonon jitter, slice binning, deposit.
+//
+// Built with -ffp-contract=off: every product/sum below rounds separately, exactly like the CPU
+// oracle, so atom coordinates, slice indices and pixel indices are bit-identical to it (the
+// wave optics downstream is compared within a float32 tolerance instead).
+//
+// Reference functions restated here (paths relative to the FDES tree):
+//   tiltCoordinates      src/crystalMaker.cu:427-454  (cublasSrot with c = cos t, s = -sin t)
+//   atomJitter(_d)       src/crystalMaker.cu:37-48, 456-462
+//   squareAtoms_d        src/crystalMaker.cu:73-134
+// Design difference: the reference re-scans ALL atoms for every (slice, species) launch
+// (O(nAt * nZ * m3) threads per configuration).  Here atoms are binned once per configuration:
+// key = slice * nZ + species, a stable radix sort (rocPRIM) makes every (slice, species) a
+// contiguous segment, and the per-slice deposit touches only its own atoms.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "geometry.h"
+#include "rng.h"
+
+namespace fdes {
+
+__global__ void k_srot(float* __restrict__ xyz, int nAt, int ax, int ay, float c, float s)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nAt; i += gridDim.x * blockDim.x) {
+        const float x = xyz[3 * i + ax], y = xyz[3 * i + ay];
+        const float cx = c * x, sy = s * y, cy = c * y, sx = s * x;
+        xyz[3 * i + ax] = cx + sy;
+        xyz[3 * i + ay] = cy - sx;
+    }
+}
+
+__global__ void k_jitter(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ dwf, int n3,
+                         uint32_t seed, uint32_t k, uint32_t j)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += gridDim.x * blockDim.x) {
+        const float x = normal(seed, 0u, k, j, (uint32_t)i);
+        const float d = (x * 0.112539540f) * sqrtf(dwf[i / 3]); // 1/(pi sqrt 8)
+        out[i] = in[i] + d;
+    }
+}
+
+// key = i3 * nZ + species for atoms that squareAtoms_d would deposit in some slice, else nkeys.
+__global__ void k_atom_keys(const float* __restrict__ xyz, const uint8_t* __restrict__ spec, int nAt, BinGeom g,
+                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nAt; i += gridDim.x * blockDim.x) {
+        const float x1 = xyz[i * 3 + 0] / g.d1 + ((float)g.m1) * 0.5f - 0.5f;
+        const float x2 = xyz[i * 3 + 1] / g.d2 + ((float)g.m2) * 0.5f - 0.5f;
+        const float z3 = roundf(xyz[i * 3 + 2] / g.d3 + ((float)g.m3) * 0.5f - 0.5f);
+        uint32_t key = (uint32_t)(g.m3 * g.nZ);
+        const bool inside = (x1 > 1.f) && (x1 < (float)(g.m1 - 2)) && (x2 > 1.f) && (x2 < (float)(g.m2 - 2));
+        if (inside && z3 >= 0.f && z3 < (float)g.m3) key = (uint32_t)((int)z3 * g.nZ + (int)spec[i]);
+        keys[i] = key;
+        vals[i] = (uint32_t)i;
+    }
+}
+
+// seg[q] = first sorted position whose key >= q, q = 0..nkeys (lower bound)
+__global__ void k_seg_bounds(const uint32_t* __restrict__ sorted, int nAt, int nkeys, int* __restrict__ seg)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nkeys) return;
+    int lo = 0, hi = nAt;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sorted[mid] < (uint32_t)q) lo = mid + 1; else hi = mid;
+    }
+    seg[q] = lo;
+}
+
+__device__ inline int signum(float x) { return x < 0.f ? -1 : 1; }
+
+// Bilinear "top-hat" deposit of one (slice, species) segment: 4 pixels x (re, im) float atomics per
+// atom.  comp selects which float2 component pair receives (w, w*imPot): the engine deposits
+// V.x = w*occ and V.y = w*occ*imPot as the reference does.
+__global__ void k_deposit(float2* __restrict__ V, const float* __restrict__ xyz, const float* __restrict__ occ,
+                          const uint32_t* __restrict__ order, const int* __restrict__ seg, int key, BinGeom g,
+                          float imPot)
+{
+    const int beg = seg[key], end = seg[key + 1];
+    for (int p = beg + blockIdx.x * blockDim.x + threadIdx.x; p < end; p += gridDim.x * blockDim.x) {
+        const int i = (int)order[p];
+        const float x1 = xyz[i * 3 + 0] / g.d1 + ((float)g.m1) * 0.5f - 0.5f;
+        const float x2 = xyz[i * 3 + 1] / g.d2 + ((float)g.m2) * 0.5f - 0.5f;
+        int i1 = (int)roundf(x1);
+        int i2 = (int)roundf(x2);
+        const float r1 = x1 - (float)i1;
+        const float r2 = x2 - (float)i2;
+        const float a1 = fabsf(r1), a2 = fabsf(r2), oc = occ[i];
+        const int s1 = signum(r1), s2 = signum(r2);
+        float w;
+        float* f = reinterpret_cast<float*>(V);
+        size_t j = (size_t)i2 * g.m1 + i1;
+        w = (1 - a1) * (1 - a2) * oc;
+        atomicAdd(f + 2 * j, w);
+        atomicAdd(f + 2 * j + 1, w * imPot);
+        i2 += s2;
+        j = (size_t)i2 * g.m1 + i1;
+        w = (1 - a1) * a2 * oc;
+        atomicAdd(f + 2 * j, w);
+        atomicAdd(f + 2 * j + 1, w * imPot);
+        i1 += s1;
+        j = (size_t)i2 * g.m1 + i1;
+        w = a1 * a2 * oc;
+        atomicAdd(f + 2 * j, w);
+        atomicAdd(f + 2 * j + 1, w * imPot);
+        i2 -= s2;
+        j = (size_t)i2 * g.m1 + i1;
+        w = a1 * (1 - a2) * oc;
+        atomicAdd(f + 2 * j, w);
+        atomicAdd(f + 2 * j + 1, w * imPot);
+    }
+}
+
+static inline int blocks_for(int n, int bs, int cap) { int b = (n + bs - 1) / bs; if (b < 1) b = 1; return b > cap ? cap : b; }
+
+hipError_t geom_srot(float* xyz, int nAt, int ax, int ay, float c, float s, hipStream_t st)
+{
+    if (nAt <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_srot, dim3(blocks_for(nAt, 256, 2048)), dim3(256), 0, st, xyz, nAt, ax, ay, c, s);
+    return hipGetLastError();
+}
+
+hipError_t geom_jitter(float* out, const float* in, const float* dwf, int nAt, uint32_t seed, int k, int j, hipStream_t st)
+{
+    if (nAt <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_jitter, dim3(blocks_for(3 * nAt, 256, 2048)), dim3(256), 0, st, out, in, dwf, 3 * nAt, seed,
+                       (uint32_t)k, (uint32_t)j);
+    return hipGetLastError();
+}
+
+size_t geom_sort_temp_bytes(int nAt)
+{
+    size_t bytes = 0;
+    uint32_t* nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, (size_t)(nAt > 0 ? nAt : 1), 0u, 32u, (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, int nAt, const BinGeom& g, AtomBins& b, hipStream_t st)
+{
+    const int nkeys = g.m3 * g.nZ;
+    if (nAt <= 0) return hipMemsetAsync(b.seg, 0, sizeof(int) * (size_t)(nkeys + 2), st);
+    hipLaunchKernelGGL(k_atom_keys, dim3(blocks_for(nAt, 256, 2048)), dim3(256), 0, st, xyz, spec, nAt, g, b.keys, b.vals);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    unsigned bits = 1;
+    while ((1u << bits) <= (unsigned)nkeys && bits < 32) bits++;
+    size_t tb = b.tmp_bytes;
+    e = rocprim::radix_sort_pairs(b.tmp, tb, b.keys, b.keys_sorted, b.vals, b.order, (size_t)nAt, 0u, bits, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_seg_bounds, dim3((nkeys + 1 + 255) / 256), dim3(256), 0, st, b.keys_sorted, nAt, nkeys, b.seg);
+    return hipGetLastError();
+}
+
+hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key, const BinGeom& g,
+                        float imPot, int blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_deposit, dim3(blocks), dim3(256), 0, st, V, xyz, occ, b.order, b.seg, key, g, imPot);
+    return hipGetLastError();
+}
+
+} // namespace fdes

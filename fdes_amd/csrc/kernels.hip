@@ -1,0 +1,479 @@
+// kernels.hip — point-wise wave-optics kernels of the FDES engine (gfx950).
+//
+// Each kernel names the reference kernel(s) it replaces (paths relative to the FDES tree).  The
+// reference launches one 1024-thread block per 1024 pixels, reads every scalar through a device
+// pointer to params_t and runs most steps as separate passes.  Here:
+// 256-thread blocks (4 waves), grid-stride over at most 2048 blocks (8 per CU), scalars by value,
+// and adjacent passes fused where that does not change the arithmetic order.
+// Data layout: float2 (re, im), idx = i2 * m1 + i1, i1 fastest (include/coordArithmetic.h:36-40).
+#include <cfloat>
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "rng.h"
+
+namespace fdes {
+
+static const float kirkland_tab[104][12] = {
+#include "kirkland_table.inc"
+};
+
+Kirk kirkland_params(int Z)
+{
+    const float* k = kirkland_tab[(Z >= 1 && Z <= 103) ? Z : 0]; // fallback row: constant 1 (projectedPotential.cu:2985)
+    Kirk r = {k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], k[9], k[10], k[11]};
+    return r;
+}
+
+#define PI_F 3.141592654f
+
+__device__ __forceinline__ int iw(int i, int m) { return (i > m / 2) ? i - m : i; } // iwCoordIp
+__device__ __forceinline__ int ow(int i, int m) { return i - m / 2; }               // owCoordIp
+
+static inline dim3 grid_for(size_t n, int bs = 256)
+{
+    size_t b = (n + bs - 1) / bs;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return dim3((unsigned)b);
+}
+#define GS_LOOP(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
+
+// ---- initialValues (src/complexMath.cu:64), cublasCsscal, cublasCaxpy --------------------------
+__global__ void kk_fill(float2* __restrict__ f, size_t n, float re, float im)
+{
+    GS_LOOP(i, n) f[i] = make_float2(re, im);
+}
+__global__ void kk_scale(float2* __restrict__ f, size_t n, float a)
+{
+    GS_LOOP(i, n) { float2 v = f[i]; v.x *= a; v.y *= a; f[i] = v; }
+}
+__global__ void kk_axpy(float2* __restrict__ y, const float2* __restrict__ x, size_t n, float a)
+{
+    GS_LOOP(i, n) { float2 v = y[i]; const float2 u = x[i]; v.x += a * u.x; v.y += a * u.y; y[i] = v; }
+}
+
+// ---- projectedPotential_d (src/projectedPotential.cu:30-73) * divideBySinc (src/crystalMaker.cu:
+// 136-158) * multiplyWithProjectedPotential_d (:160-172) + cublasCaxpy (:532), in Fourier space.
+// The reference materialises f_e(q) per slice and species and sums the species in real space after
+// nZ inverse FFTs; the sum commutes with the (linear) inverse FFT, so it is taken here.
+__global__ void kk_filter_accum(float2* __restrict__ Vh, float2* __restrict__ Dh, KP p, Kirk kz, int first)
+{
+    const size_t n = (size_t)p.m1 * p.m2;
+    const float d1 = 1e10f * p.d1, d2 = 1e10f * p.d2;
+    const float scale = (4.78776452e-9f * p.sigma) / (d1 * d2 * ((float)(p.m1 * p.m2)));
+    GS_LOOP(i, n)
+    {
+        const int j1 = (int)(i % (size_t)p.m1), j2 = (int)(i / (size_t)p.m1);
+        const int i1 = iw(j1, p.m1), i2 = iw(j2, p.m2);
+        float qsq = ((float)i1) / (d1 * ((float)p.m1));
+        float Vz = ((float)i2) / (d2 * ((float)p.m2));
+        qsq = qsq * qsq + Vz * Vz;
+        Vz = kz.a0 / (qsq + kz.b0) + kz.c0 * expf(-kz.d0 * qsq);
+        Vz += kz.a1 / (qsq + kz.b1) + kz.c1 * expf(-kz.d1 * qsq);
+        Vz += kz.a2 / (qsq + kz.b2) + kz.c2 * expf(-kz.d2 * qsq);
+        float g = Vz * scale;
+        float y = PI_F;
+        float x = ((float)i1) / ((float)p.m1) * y;
+        x = (x + FLT_EPSILON) / (sinf(x) + FLT_EPSILON);
+        y *= ((float)i2) / ((float)p.m2);
+        x *= (y + FLT_EPSILON) / (sinf(y) + FLT_EPSILON);
+        g *= x;
+        const float2 d = Dh[i];
+        float2 v = first ? make_float2(0.f, 0.f) : Vh[i];
+        v.x += d.x * g;
+        v.y += d.y * g;
+        Vh[i] = v;
+        Dh[i] = make_float2(0.f, 0.f); // ready for the next deposit (initialValues, :522)
+    }
+}
+
+// Same filter as kk_filter_accum, tabulated once per plan and species (it does not depend on the
+// slice): g_Z(q) = f_e(q^2) * 4.78776452e-9 sigma / (d1 d2 m12) * x/sin x * y/sin y.
+__global__ void kk_gtab(float* __restrict__ G, KP p, Kirk kz, int transposed)
+{
+    const size_t n = (size_t)p.m1 * p.m2;
+    const float d1 = 1e10f * p.d1, d2 = 1e10f * p.d2;
+    const float scale = (4.78776452e-9f * p.sigma) / (d1 * d2 * ((float)(p.m1 * p.m2)));
+    GS_LOOP(i, n)
+    {
+        const int j1 = transposed ? (int)(i / (size_t)p.m2) : (int)(i % (size_t)p.m1);
+        const int j2 = transposed ? (int)(i % (size_t)p.m2) : (int)(i / (size_t)p.m1);
+        const int i1 = iw(j1, p.m1), i2 = iw(j2, p.m2);
+        float qsq = ((float)i1) / (d1 * ((float)p.m1));
+        float Vz = ((float)i2) / (d2 * ((float)p.m2));
+        qsq = qsq * qsq + Vz * Vz;
+        Vz = kz.a0 / (qsq + kz.b0) + kz.c0 * expf(-kz.d0 * qsq);
+        Vz += kz.a1 / (qsq + kz.b1) + kz.c1 * expf(-kz.d1 * qsq);
+        Vz += kz.a2 / (qsq + kz.b2) + kz.c2 * expf(-kz.d2 * qsq);
+        float g = Vz * scale;
+        float y = PI_F;
+        float x = ((float)i1) / ((float)p.m1) * y;
+        x = (x + FLT_EPSILON) / (sinf(x) + FLT_EPSILON);
+        y *= ((float)i2) / ((float)p.m2);
+        x *= (y + FLT_EPSILON) / (sinf(y) + FLT_EPSILON);
+        G[i] = g * x;
+    }
+}
+
+// ---- potential2Transmission (src/multisliceSimulation.cu:41-52) -------------------------------
+__global__ void kk_transmit(float2* __restrict__ t, const float2* __restrict__ V, size_t n)
+{
+    GS_LOOP(i, n)
+    {
+        const float2 v = V[i];
+        const float a = expf(-v.y);
+        float s, c;
+        sincosf(v.x, &s, &c);
+        t[i] = make_float2(a * c, a * s);
+    }
+}
+
+// ---- zeroHighFreq (src/multisliceSimulation.cu:225-250) fused with the cublasCsscal that follows
+// it in bandwidthLimit (:557-559; the scale commutes with the inverse FFT in between) ----------
+__device__ __forceinline__ bool outside_band(int i1, int i2, float mindim)
+{
+    return ((float)(i1 * i1 + i2 * i2) * 9.f / (mindim * mindim)) > 1.f;
+}
+__global__ void kk_mask_scale(float2* __restrict__ f, int m1, int m2, float alpha)
+{
+    const size_t n = (size_t)m1 * m2;
+    const float mindim = (float)(m1 < m2 ? m1 : m2);
+    GS_LOOP(i, n)
+    {
+        const int i1 = iw((int)(i % (size_t)m1), m1), i2 = iw((int)(i / (size_t)m1), m2);
+        float2 v = f[i];
+        if (outside_band(i1, i2, mindim)) v = make_float2(0.f, 0.f);
+        else { v.x *= alpha; v.y *= alpha; }
+        f[i] = v;
+    }
+}
+
+// ---- multiplyElementwise (src/complexMath.cu:44-62): 3-multiply product, f0 = (a, b), f1 = (c, d)
+__device__ __forceinline__ float2 cmul3(float2 f0, float2 f1)
+{
+    const float a = f0.x, b = f0.y;
+    float c = f1.x, d = f1.y;
+    const float k = a * (c + d);
+    d *= a + b;
+    c *= b - a;
+    return make_float2(k - d, k + c);
+}
+__global__ void kk_mul(float2* __restrict__ dst, const float2* __restrict__ f0, const float2* __restrict__ f1, size_t n)
+{
+    GS_LOOP(i, n) dst[i] = cmul3(f0[i], f1[i]);
+}
+
+// ---- fresnelPropagatorDevice + zeroHighFreq + Csscal (src/multisliceSimulation.cu:253-274, 594-603)
+// The reference rebuilds this table every slice; it only depends on the plan.
+// transposed != 0: element (kx, ky) is stored at kx * m2 + ky (layout of the fused LDS passes).
+__global__ void kk_propagator(float2* __restrict__ P, KP p, int transposed)
+{
+    const size_t n = (size_t)p.m1 * p.m2;
+    const float mindim = (float)(p.m1 < p.m2 ? p.m1 : p.m2);
+    const float alpha = 1.f / ((float)(p.m1 * p.m2));
+    GS_LOOP(i, n)
+    {
+        const int j1 = transposed ? (int)(i / (size_t)p.m2) : (int)(i % (size_t)p.m1);
+        const int j2 = transposed ? (int)(i % (size_t)p.m2) : (int)(i / (size_t)p.m1);
+        const int i1 = iw(j1, p.m1), i2 = iw(j2, p.m2);
+        float d3 = p.d3;
+        const float t1 = ((float)(i1) / ((float)p.m1)) * (d3 / p.d1);
+        const float t2 = ((float)(i2) / ((float)p.m2)) * (d3 / p.d2);
+        d3 = p.lambda / d3;
+        d3 = -PI_F * (t1 * t1 + t2 * t2) * d3;
+        float2 v = make_float2(cosf(d3), sinf(d3));
+        if (outside_band(i1, i2, mindim)) v = make_float2(0.f, 0.f);
+        v.x *= alpha;
+        v.y *= alpha;
+        P[i] = v;
+    }
+}
+
+// ---- multiplyLensFunction (src/multisliceSimulation.cu:277-343) --------------------------------
+__global__ void kk_lens(float2* __restrict__ psi, KP p, float defocus_k)
+{
+    const size_t n = (size_t)p.m1 * p.m2;
+    const fdes_aberration ab = p.ab;
+    GS_LOOP(i, n)
+    {
+        const int i1 = iw((int)(i % (size_t)p.m1), p.m1);
+        const int i2 = -iw((int)(i / (size_t)p.m1), p.m2); // row index points up
+        float nu = (((float)i1) / ((float)p.m1)) * (p.lambda / p.d1);
+        float nu2 = (((float)i2) / ((float)p.m2)) * (p.lambda / p.d2);
+        float phi = atan2f(nu2, nu);
+        nu = sqrtf(nu * nu + nu2 * nu2);
+        float2 out = make_float2(0.f, 0.f);
+        if (nu < p.ObjAp) {
+            const float W =
+                nu * nu *
+                (0.5f * (ab.A1_0 * cosf(2.f * (phi - ab.A1_1)) + ab.C1_0 + defocus_k) +
+                 nu * (1.f / 3.f * (ab.A2_0 * cosf(3.f * (phi - ab.A2_1)) + ab.B2_0 * cosf(phi - ab.B2_1)) +
+                       nu * (0.25f * (ab.A3_0 * cosf(4.f * (phi - ab.A3_1)) + ab.S3_0 * cosf(2.f * (phi - ab.S3_1)) + ab.C3_0) +
+                             nu * (0.2f * (ab.A4_0 * cosf(5.f * (phi - ab.A4_1)) + ab.B4_0 * cosf(phi - ab.B4_1) +
+                                           ab.D4_0 * cosf(3.f * (phi - ab.D4_1))) +
+                                   nu * (1.f / 6.f *
+                                         (ab.A5_0 * cosf(6.f * (phi - ab.A5_1)) + ab.R5_0 * cosf(4.f * (phi - ab.R5_1)) +
+                                          ab.S5_0 * cosf(2.f * (phi - ab.S5_1)) + ab.C5_0))))));
+            nu2 = p.lambda;
+            float damp = 1.f;
+            if (p.mode == 0) {
+                damp = p.defocspread * nu * nu / nu2;
+                damp = expf(-2.f * damp * damp);
+            }
+            nu = PI_F;
+            phi = damp * cosf(2.f * nu * (W / nu2));
+            damp = damp * sinf(-2.f * nu * (W / nu2));
+            const float2 v = psi[i];
+            out.x = phi * v.x - damp * v.y;
+            out.y = phi * v.y + damp * v.x;
+        }
+        psi[i] = out;
+    }
+}
+
+// ---- cublasCsscal(1/m12) of applyLensFunction (:621) / sqrt(1/m12) of diffractionPattern
+// (src/crystalMaker.cu:716) + intensityValues (src/multisliceSimulation.cu:346-359) + cublasCaxpy
+// into the running sum (src/crystalMaker.cu:353,359,365) -----------------------------------------
+__global__ void kk_intensity_axpy(float2* __restrict__ I, const float2* __restrict__ psi, size_t n, float pre, float alpha)
+{
+    GS_LOOP(i, n)
+    {
+        float2 v = psi[i];
+        v.x *= pre;
+        v.y *= pre;
+        const float q = v.x * v.x + v.y * v.y;
+        float2 a = I[i];
+        a.x += alpha * q;
+        a.y += alpha * 0.f;
+        I[i] = a;
+    }
+}
+
+// ---- tiltBeam_d (src/multisliceSimulation.cu:89-120) -------------------------------------------
+__global__ void kk_tilt_beam(float2* __restrict__ psi, KP p, float tb0, float tb1, int flag)
+{
+    const size_t n = (size_t)p.m1 * p.m2;
+    GS_LOOP(i, n)
+    {
+        const int i1 = ow((int)(i % (size_t)p.m1), p.m1), i2 = ow((int)(i / (size_t)p.m1), p.m2);
+        float x2 = p.lambda * ((float)flag);
+        float x1 = ((float)i1) * (p.d1 / x2) * tb1;
+        x2 = ((float)i2) * (p.d2 / x2) * tb0;
+        x1 = 2.f * PI_F * (x1 + x2);
+        x2 = sinf(x1);
+        x1 = cosf(x1);
+        const float2 v = psi[i];
+        psi[i] = make_float2(x1 * v.x - x2 * v.y, x2 * v.x + x1 * v.y);
+    }
+}
+
+// ---- taperedCosineWindow_d (src/multisliceSimulation.cu:123-156) --------------------------------
+__device__ __forceinline__ float tukey1(int i, int dim, int dn)
+{
+    float w = 1.f;
+    const float alpha = 2.f * (((float)dn) / ((float)dim));
+    const float x = ((float)i) / ((float)(dim - 1));
+    if (x < alpha * 0.5f) w = 0.5f * (1.f + cosf(PI_F * (2.f * x / alpha - 1.f)));
+    else if (x > 1.f - 0.5f * alpha) w = 0.5f * (1.f + cosf(PI_F * (2.f * x / alpha + 1.f - 2.f / alpha)));
+    return w;
+}
+__global__ void kk_tukey(float2* __restrict__ psi, KP p)
+{
+    const size_t n = (size_t)p.m1 * p.m2;
+    GS_LOOP(i, n)
+    {
+        float w = tukey1((int)(i % (size_t)p.m1), p.m1, p.dn1);
+        w *= tukey1((int)(i / (size_t)p.m1), p.m2, p.dn2);
+        float2 v = psi[i];
+        v.x *= w;
+        v.y *= w;
+        psi[i] = v;
+    }
+}
+
+// ---- cufftShift2D_h (src/complexMath.cu:510-557): 4 strip kernels x 64 strips -> one out-of-place pass
+__global__ void kk_fftshift(float2* __restrict__ out, const float2* __restrict__ in, int m1, int m2)
+{
+    const size_t n = (size_t)m1 * m2;
+    GS_LOOP(i, n)
+    {
+        const int i1 = (int)(i % (size_t)m1), i2 = (int)(i / (size_t)m1);
+        const int j1 = (i1 < m1 - m1 / 2) ? i1 + m1 / 2 : i1 - (m1 - m1 / 2);
+        const int j2 = (i2 < m2 - m2 / 2) ? i2 + m2 / 2 : i2 - (m2 - m2 / 2);
+        out[(size_t)j2 * m1 + j1] = in[i];
+    }
+}
+
+// ---- areaMask + areaWeighting (src/multisliceSimulation.cu:468-510, src/crystalMaker.cu:187-224)
+__global__ void kk_mask_filter(float2* __restrict__ psi, KP p)
+{
+    const size_t n = (size_t)p.m1 * p.m2;
+    GS_LOOP(i, n)
+    {
+        const int i1 = (int)(i % (size_t)p.m1), i2 = (int)(i / (size_t)p.m1);
+        float w = 1.f;
+        if (i1 <= p.dn1 - 1) w *= 0.5f * (1 - cosf(3.1415927f * (float)i1 / (float)p.dn1));
+        if (i1 >= p.m1 - p.dn1) w *= 0.5f * (1 - cosf(3.1415927f * (float)(p.m1 - i1) / (float)p.dn1));
+        if (i2 <= p.dn2 - 1) w *= 0.5f * (1 - cosf(3.1415927f * (float)i2 / (float)p.dn2));
+        if (i2 >= p.m2 - p.dn2) w *= 0.5f * (1 - cosf(3.1415927f * (float)(p.m2 - i2) / (float)p.dn2));
+        const float2 v = psi[i];
+        psi[i] = make_float2(1.f * (1 - w) + v.x * w, 0.f * (1 - w) + v.y * w);
+    }
+}
+
+// ---- multiplySpatialIncoherence / ...DP (src/multisliceSimulation.cu:391-442) -------------------
+__global__ void kk_spatial(float2* __restrict__ f, KP p, float defocus_k, int dp)
+{
+    const size_t n = (size_t)p.m1 * p.m2;
+    GS_LOOP(i, n)
+    {
+        const int i1 = iw((int)(i % (size_t)p.m1), p.m1), i2 = iw((int)(i / (size_t)p.m1), p.m2);
+        float damp;
+        if (!dp) {
+            damp = p.lambda;
+            float nusq = (((float)i1) / ((float)p.m1)) * (damp / p.d1);
+            damp = (((float)i2) / ((float)p.m2)) * (damp / p.d2);
+            nusq = nusq * nusq + damp * damp;
+            damp = PI_F * p.illangle * defocus_k;
+            damp = expf(-nusq * damp * damp);
+        } else {
+            float x1 = ((float)i1) * p.d1;
+            float x2 = ((float)i2) * p.d2;
+            x1 = x1 * x1 + x2 * x2;
+            x2 = PI_F * p.illangle / p.lambda;
+            damp = expf(-x2 * x2 * x1);
+        }
+        float2 v = f[i];
+        v.x *= damp;
+        v.y *= damp;
+        f[i] = v;
+    }
+}
+
+// ---- multiplyMtf (src/multisliceSimulation.cu:362-388) + the cublasCsscal after it (crystalMaker.cu:609)
+__global__ void kk_mtf(float2* __restrict__ f, KP p, float alpha)
+{
+    const size_t n = (size_t)p.m1 * p.m2;
+    GS_LOOP(i, n)
+    {
+        const int i1 = iw((int)(i % (size_t)p.m1), p.m1), i2 = iw((int)(i / (size_t)p.m1), p.m2);
+        float nu1 = ((float)i1) / ((float)p.m1);
+        float nu2 = ((float)i2) / ((float)p.m2);
+        float mtf = sqrtf(nu1 * nu1 + nu2 * nu2);
+        mtf = (p.mtfa * expf(-p.mtfc * mtf) + p.mtfb * expf(-p.mtfd * mtf * mtf));
+        nu1 *= PI_F;
+        nu2 *= PI_F;
+        mtf *= ((sinf(nu1) + FLT_EPSILON) / (nu1 + FLT_EPSILON)) * ((sinf(nu2) + FLT_EPSILON) / (nu2 + FLT_EPSILON));
+        float2 v = f[i];
+        v.x = (v.x * mtf) * alpha;
+        v.y = (v.y * mtf) * alpha;
+        f[i] = v;
+    }
+}
+
+// ---- ascombeNoise_d (src/crystalMaker.cu:50-70); deviates from Philox stream 1, key (seed, k, pixel)
+__global__ void kk_noise(float2* __restrict__ f, size_t n, float dose, uint32_t seed, uint32_t k)
+{
+    GS_LOOP(i, n)
+    {
+        float2 v = f[i];
+        const float fi = v.x * dose;
+        if (fi > 1e-2f) {
+            float x = normal(seed, 1u, k, 0u, (uint32_t)i);
+            x *= sqrtf(1 - expf(-fi / 0.777134f));
+            x += 2.f * sqrtf(fi + 0.375f) - 0.25f / sqrtf(fi);
+            x = roundf(0.25f * x * x - 0.375f);
+            if (x < FLT_MIN) x = 0.f;
+            v.x = x / dose;
+            f[i] = v;
+        }
+    }
+}
+
+// ---- copyMiddleOut (src/optimFunctions.cu:109-121) ---------------------------------------------
+__global__ void kk_crop(float* __restrict__ J, const float2* __restrict__ I, KP p)
+{
+    const size_t n = (size_t)p.n1 * p.n2;
+    GS_LOOP(j, n)
+    {
+        const int i1 = (int)(j % (size_t)p.n1), i2 = (int)(j / (size_t)p.n1);
+        J[j] = I[(size_t)(i1 + p.dn1) + (size_t)p.m1 * (i2 + p.dn2)].x;
+    }
+}
+
+// ---- cublasScnrm2 + Csscal of the CBED probe (src/multisliceSimulation.cu:578-580) -------------
+__global__ void kk_sumsq(const float2* __restrict__ f, size_t n, float* __restrict__ acc)
+{
+    float s = 0.f;
+    GS_LOOP(i, n) { const float2 v = f[i]; s += v.x * v.x + v.y * v.y; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) part[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ void kk_scale_by(float2* __restrict__ f, size_t n, float target, const float* __restrict__ acc)
+{
+    const float a = target / sqrtf(*acc);
+    GS_LOOP(i, n) { float2 v = f[i]; v.x *= a; v.y *= a; f[i] = v; }
+}
+
+#define LAUNCH(kern, n, st, ...)                                                \
+    do {                                                                        \
+        hipLaunchKernelGGL(kern, grid_for(n), dim3(256), 0, st, __VA_ARGS__);   \
+        return hipGetLastError();                                               \
+    } while (0)
+
+hipError_t k_fill(float2* f, size_t n, float re, float im, hipStream_t st) { LAUNCH(kk_fill, n, st, f, n, re, im); }
+hipError_t k_scale(float2* f, size_t n, float a, hipStream_t st) { LAUNCH(kk_scale, n, st, f, n, a); }
+hipError_t k_axpy(float2* y, const float2* x, size_t n, float a, hipStream_t st) { LAUNCH(kk_axpy, n, st, y, x, n, a); }
+hipError_t k_filter_accum(float2* Vh, float2* Dh, const KP& p, const Kirk& kz, int first, hipStream_t st)
+{
+    LAUNCH(kk_filter_accum, (size_t)p.m1 * p.m2, st, Vh, Dh, p, kz, first);
+}
+hipError_t k_transmit(float2* t, const float2* V, size_t n, hipStream_t st) { LAUNCH(kk_transmit, n, st, t, V, n); }
+hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st)
+{
+    LAUNCH(kk_mask_scale, (size_t)m1 * m2, st, f, m1, m2, alpha);
+}
+hipError_t k_mul(float2* dst, const float2* f0, const float2* f1, size_t n, hipStream_t st) { LAUNCH(kk_mul, n, st, dst, f0, f1, n); }
+hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_t st) { LAUNCH(kk_propagator, (size_t)p.m1 * p.m2, st, P, p, transposed); }
+hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, hipStream_t st) { LAUNCH(kk_gtab, (size_t)p.m1 * p.m2, st, G, p, kz, transposed); }
+hipError_t k_lens(float2* psi, const KP& p, float dk, hipStream_t st) { LAUNCH(kk_lens, (size_t)p.m1 * p.m2, st, psi, p, dk); }
+hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre, float alpha, hipStream_t st)
+{
+    LAUNCH(kk_intensity_axpy, n, st, I, psi, n, pre, alpha);
+}
+hipError_t k_tilt_beam(float2* psi, const KP& p, float tb0, float tb1, int flag, hipStream_t st)
+{
+    LAUNCH(kk_tilt_beam, (size_t)p.m1 * p.m2, st, psi, p, tb0, tb1, flag);
+}
+hipError_t k_tukey(float2* psi, const KP& p, hipStream_t st) { LAUNCH(kk_tukey, (size_t)p.m1 * p.m2, st, psi, p); }
+hipError_t k_fftshift(float2* out, const float2* in, int m1, int m2, hipStream_t st)
+{
+    LAUNCH(kk_fftshift, (size_t)m1 * m2, st, out, in, m1, m2);
+}
+hipError_t k_mask_filter(float2* psi, const KP& p, hipStream_t st) { LAUNCH(kk_mask_filter, (size_t)p.m1 * p.m2, st, psi, p); }
+hipError_t k_spatial_incoherence(float2* f, const KP& p, float dk, int dp, hipStream_t st)
+{
+    LAUNCH(kk_spatial, (size_t)p.m1 * p.m2, st, f, p, dk, dp);
+}
+hipError_t k_mtf(float2* f, const KP& p, float alpha, hipStream_t st) { LAUNCH(kk_mtf, (size_t)p.m1 * p.m2, st, f, p, alpha); }
+hipError_t k_noise(float2* f, size_t n, float dose, uint32_t seed, int k, hipStream_t st)
+{
+    LAUNCH(kk_noise, n, st, f, n, dose, seed, (uint32_t)k);
+}
+hipError_t k_crop(float* J, const float2* I, const KP& p, hipStream_t st) { LAUNCH(kk_crop, (size_t)p.n1 * p.n2, st, J, I, p); }
+hipError_t k_normalize_to(float2* f, size_t n, float target, float* scratch, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kk_sumsq, grid_for(n), dim3(256), 0, st, f, n, scratch);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(kk_scale_by, grid_for(n), dim3(256), 0, st, f, n, target, scratch);
+    return hipGetLastError();
+}
+
+} // namespace fdes

@@ -1,0 +1,88 @@
+// run_file.cpp — file-level entry points: the legacy `FDES(...)` export of the reference's
+// shared library (src/FDESExport.cu:59-178) and its int-returning twin, shared with the CLI
+// (src/FDES.cu:61-263).  Host C++ only; the GPU work happens behind fdes_build_measurements.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "fdes_internal.h"
+
+namespace {
+bool has_ext(const char* name, const char* ext) { return std::strstr(name, ext) != nullptr; }
+}
+
+extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_name, const char* image_name,
+                             const char* emd_name, const float* atomsArray, int numAtoms, float* dstImage)
+{
+    if (!input_name) return FDES_EINVAL;
+    if (print_level < 0 || print_level > 2) return FDES_EINVAL;
+    // dispatch by extension (src/FDES.cu:107-118, src/FDESExport.cu:84-101)
+    if (has_ext(input_name, ".emd") || has_ext(input_name, ".qsc")) {
+        std::fprintf(stderr, "  FDES: input '%s': only .cnf inputs are handled by this build (.emd/.qsc front-ends: INTEGRATION.md)\n", input_name);
+        return FDES_EUNSUPPORTED;
+    }
+    if (!has_ext(input_name, ".cnf")) {
+        std::fprintf(stderr, "  FDES: input file %s: unknown extension\n", input_name);
+        return FDES_EINVAL;
+    }
+    fdes_params p0;
+    int rc = fdes_params_init(&p0, 1000); // allocParams(&params0, 1000), src/paramStructure.cu:604-606
+    if (rc) return rc;
+    fdes_atoms atoms = {0, nullptr, nullptr, nullptr, nullptr};
+    const bool external = atomsArray != nullptr; // atomsFromExternal, src/FDESExport.cu:73
+    int flags = FDES_CNF_BUG_COMPATIBLE | (external ? FDES_CNF_SKIP_ATOMS : 0);
+    if (std::getenv("FDES_STRICT_CNF")) flags &= ~FDES_CNF_BUG_COMPATIBLE;
+    rc = fdes_read_cnf(input_name, &p0, &atoms, flags);
+    if (rc) {
+        std::fprintf(stderr, "  FDES: cannot read simulation configuration from %s (%d)\n", input_name, rc);
+        fdes_params_release(&p0);
+        return rc;
+    }
+    if (external) {
+        rc = fdes_atoms_from_array(&atoms, atomsArray, numAtoms, /*truncate_occ=*/1); // src/paramStructure.cu:323
+        if (rc) { fdes_params_release(&p0); return rc; }
+        p0.nAt = numAtoms;
+    }
+    std::fprintf(stderr, "  Number of atoms in the specimen: %i\n", atoms.nAt);
+    rc = fdes_params_consistent(&p0);
+    if (rc == FDES_OK) fdes_write_cnf("dataFDES_used.cnf", &p0, &atoms); // src/paramStructure.cu:629-631
+    std::vector<float> image, potential, exitwave;
+    fdes_ctx* ctx = nullptr;
+    if (rc == FDES_OK) {
+        rc = fdes_create(&ctx, gpu_index);
+        if (rc) std::fprintf(stderr, "  FDES: no usable GPU with index %d\n", gpu_index);
+    }
+    if (rc == FDES_OK) {
+        const size_t m12 = (size_t)p0.m1 * p0.m2;
+        image.resize((size_t)p0.n1 * p0.n2 * p0.n3);
+        if (print_level > 0) potential.resize(2 * m12 * (size_t)p0.m3);
+        if (print_level > 1) exitwave.resize(2 * m12 * (size_t)p0.n3);
+        rc = fdes_build_measurements(ctx, &p0, &atoms, image.data(), print_level > 0 ? potential.data() : nullptr,
+                                     print_level > 1 ? exitwave.data() : nullptr);
+        if (rc) std::fprintf(stderr, "  FDES: simulation failed: %s\n", fdes_last_error(ctx));
+    }
+    if (rc == FDES_OK) {
+        if (image_name) rc = fdes_write_binary(image_name, image.data(), image.size()); // src/crystalMaker.cu:399
+        if (rc == FDES_OK && emd_name) {
+            int e = fdes_write_emd(emd_name, &p0, &atoms, image.data(), print_level > 0 ? potential.data() : nullptr,
+                                   print_level > 1 ? exitwave.data() : nullptr, print_level); // :402
+            if (e == FDES_EUNSUPPORTED) std::fprintf(stderr, "  FDES: libhdf5 not available, %s not written\n", emd_name);
+            else if (e) rc = e;
+        }
+        if (dstImage) std::memcpy(dstImage, image.data(), sizeof(float) * image.size()); // exportFormedimage
+    }
+    if (ctx) fdes_destroy(ctx);
+    fdes_atoms_release(&atoms);
+    fdes_params_release(&p0);
+    return rc;
+}
+
+// Same symbol, same arguments as src/FDESExport.cu:59-60.  Never exits the host process.
+extern "C" void FDES(int gpu_Index, int print_Level, char* input_name, char* image_name, char* emd_save_name,
+                     float* atomsArray, int numAtoms, float* dstImage)
+{
+    std::fprintf(stderr, "   input_name %s  \n", input_name ? input_name : "(null)");
+    int rc = fdes_run_file(gpu_Index, print_Level, input_name, image_name, emd_save_name, atomsArray, numAtoms, dstImage);
+    if (rc) std::fprintf(stderr, "  FDES: failed with code %d\n", rc);
+}

@@ -143,17 +143,28 @@ int fdes_plan_end_measurement(fdes_plan* plan, int k);
 /* Device pointer of the running intensity sum I (float2[m1*m2], .y = 0) so that the host
  * can reduce it across ranks (RCCL) between run_config and end_measurement. */
 int fdes_plan_intensity_ptr(fdes_plan* plan, void** dev_ptr, size_t* bytes);
+/* D2D copy of I into (to_plan = 0) or from (to_plan = 1) a caller-owned DEVICE buffer of the size
+ * fdes_plan_intensity_ptr reports; stream-ordered with the plan's work, synchronises before return.
+ * Lets a host runtime (torch.distributed / RCCL) reduce I without aliasing library memory. */
+int fdes_plan_copy_intensity(fdes_plan* plan, void* dev_buf, int to_plan);
 /* Device pointer to J (float[n1*n2*n3]). */
 int fdes_plan_images_ptr(fdes_plan* plan, void** dev_ptr, size_t* bytes);
 /* D2H of J (:375). Synchronises. */
 int fdes_plan_get_images(fdes_plan* plan, float* image);
 int fdes_plan_sync(fdes_plan* plan);
+/* 1: generic slice loop on rocFFT + point-wise kernels; 2: fused LDS-pass slice loop. */
+int fdes_plan_fft_backend(const fdes_plan* plan);
 /* Number of (sub-)slices m3 after sub-slicing; slice-propagations done so far. */
 int fdes_plan_num_slices(const fdes_plan* plan);
 int64_t fdes_plan_slices_done(const fdes_plan* plan);
 /* Mean device time [ms] of the slice loops between the HIP events recorded by
  * run_config since the last call (measurement). Synchronises. */
 int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
+
+/* Sum of the HIP-event durations [ms] of the probed launches of the dominant kernel (option
+ * "probe_stride" = n > 0 brackets every n-th 2-D FFT with events on the plan's stream) since the
+ * last call, and how many were probed.  Synchronises. */
+int fdes_plan_probe_ms(fdes_plan* plan, double* total_ms, int64_t* launches);
 
 /* ---- stage taps for parity tests (device results copied to HOST buffers) ---- */
 /* Atom coordinates used by configuration (k, j): tilt offset, tilt k, jitter. float[3*nAt]. */
@@ -172,10 +183,16 @@ int fdes_plan_tap_propagator(fdes_plan* plan, float* P);
  * t is shared (batch stride 0) or per-wave.  (src/multisliceSimulation.cu:546-548) */
 int fdes_plan_propagate_dev(fdes_plan* plan, void* psi_dev, const void* t_dev, int batch, int t_per_wave);
 
+/* Unnormalised 2-D C2C FFT of a HOST grid (float[2*m1*m2], idx = i2*m1 + i1) through the engine's FFT
+ * back-end (cufftExecC2C stand-in; test hook).  backend: 0 auto, 1 rocFFT, 2 LDS kernels.
+ * Returns the back-end used (1 or 2) or a negative error. */
+int fdes_fft2d_host(fdes_ctx* ctx, float* data, int m1, int m2, int inverse, int backend);
+
 /* Engine options (before fdes_plan_create).  Unknown keys -> FDES_EINVAL.
  *   "fft"        0 = auto, 1 = rocFFT, 2 = hand-written LDS FFT kernels (power-of-two grids)
  *   "graph"      1 = replay the slice loop from a hipGraph
- *   "seed"       frozen-phonon seed (reference: 1, src/crystalMaker.cu:292)              */
+ *   "seed"       frozen-phonon seed (reference: 1, src/crystalMaker.cu:292)
+ *   "probe_stride"  see fdes_plan_probe_ms                                                  */
 int fdes_set_option(fdes_ctx* ctx, const char* key, int64_t value);
 
 /* ---------------- legacy symbol ---------------- */

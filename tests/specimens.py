@@ -109,3 +109,14 @@ def case_c5(k=60, frPh=16):
     hp = make_params(1, E0=50e3, n1=2048, n2=2048, dn1=1024, dn2=1024, d1=0.25e-10, d2=0.25e-10, m3=512,
                      d3=0.5e-10, subSlTh=0.5e-10, mode=0, frPh=frPh, pD=0.0)
     return hp, HostAtoms(np.full(len(xyz), 79, np.int32), xyz, 6e-21, 1.0)
+
+
+# parameter sets of the committed golden images (tests/golden/tiny_cases.npz, tools/make_golden.py)
+GOLDEN_CASES = {
+    "img_2sp": dict(m=64, m3=4, nz=2, mode=0),
+    "img_tilt_beam": dict(m=64, m3=4, nz=3, mode=0, n3=2, tilt=True, beam_tilt=True),
+    "dp": dict(m=64, m3=4, nz=2, mode=1, n3=1, beam_tilt=True),
+    "cbed": dict(m=64, m3=4, nz=2, mode=2),
+    "phonon_sub3": dict(m=64, m3=3, nz=2, frPh=3, sub=3),
+    "rect": dict(m=96, m3=3, nz=2, rect=True),
+}

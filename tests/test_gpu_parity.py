@@ -1,0 +1,246 @@
+"""GPU parity tests: the HIP engine (through the C-ABI) against the CPU oracle on the same inputs.
+
+Stated tolerance (float32 wave optics, deterministic configurations): with
+E(x) = ||x - truth_f64||_2 / ||truth_f64||_2,
+    E(gpu) <= 1e-5 for <= 16 slices, E(gpu) <= 1e-4 up to 512 slices,
+    max |gpu - truth| <= 1e-3 * max(truth),
+and E(gpu) is printed beside E(cpu_f32) of the float32 oracle.  Atom geometry (tilts, frozen-phonon
+displacements, slice binning) must be BIT-EXACT against the oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import fdes_amd
+from tests import specimens as S
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def relerr(a, b):
+    dt = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
+    return float(np.linalg.norm(np.asarray(a, dt) - np.asarray(b, dt)) / np.linalg.norm(b))
+
+
+def check(gpu, f64, f32=None, tol=1e-5, what=""):
+    e = relerr(gpu, f64)
+    e32 = relerr(f32, f64) if f32 is not None else float("nan")
+    print(f"[parity] {what}: E(gpu)={e:.3e} E(cpu_f32)={e32:.3e}")
+    assert e <= tol, (what, e, e32)
+    assert np.abs(np.asarray(gpu) - f64).max() <= 1e-3 * np.abs(f64).max(), what
+
+
+def test_library_is_the_hip_one():
+    lib = fdes_amd.load_library()
+    assert lib.fdes_gpu_available() == 1
+    assert lib.fdes_abi_version() == 1
+
+
+def test_coordinates_bit_exact(engine, oracle):
+    hp, at = S.case_tiny(m=64, m3=4, nz=3, n3=3, tilt=True, frPh=2)
+    fdes_amd.consistent(hp)
+    q, _ = oracle.sub_sliced(oracle.consistent(hp.copy()))
+    pl = engine.plan(hp, at)
+    for (k, j) in [(-1, -1), (0, -1), (2, -1), (0, 0), (1, 1), (2, 0)]:
+        g = pl.tap_coords(k, j)
+        o = oracle.config_coords(q, at, k, j)
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), (k, j)
+    pl.close()
+
+
+def test_params_consistent_matches_oracle(oracle):
+    for E0 in (40e3, 50e3, 80e3, 100e3, 200e3, 300e3):
+        a = fdes_amd.consistent(S.make_params(2, E0=E0, tiltbeam=[0, 0, 1e-3, 0]))
+        b = oracle.consistent(S.make_params(2, E0=E0, tiltbeam=[0, 0, 1e-3, 0]))
+        for f in ("gamma", "lambda_", "sigma", "m1", "m2", "doBeamTilt"):
+            assert getattr(a.c, f) == getattr(b.c, f), (E0, f)
+
+
+def test_propagator(engine, oracle):
+    for kw in (dict(m=64), dict(m=96, rect=True)):
+        hp, at = S.case_tiny(m3=3, nz=1, **kw)
+        fdes_amd.consistent(hp)
+        q, _ = oracle.sub_sliced(hp)
+        pl = engine.plan(hp, at)
+        P = pl.tap_propagator()
+        ref = oracle.fresnel_propagator(q, "f64")
+        assert np.array_equal(P == 0, ref == 0)  # same band-limit mask
+        check(P, ref, oracle.fresnel_propagator(q, "f32"), 1e-6, "propagator")
+        pl.close()
+
+
+@pytest.mark.parametrize("kw", [dict(m=64, nz=1), dict(m=64, nz=3), dict(m=96, nz=2, rect=True), dict(m=60, nz=2),
+                                dict(m=100, nz=2, rect=True)])
+def test_potential_per_slice(engine, oracle, kw):
+    hp, at = S.case_tiny(m3=4, tilt=True, **kw)
+    fdes_amd.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    xyz = oracle.config_coords(q, at, 0, -1)
+    pl = engine.plan(hp, at)
+    for s in range(q.c.m3):
+        V = pl.tap_potential(0, 0, s)
+        ref = oracle.phase_grating(q, at, xyz, s, "f64")
+        if np.abs(ref).max() == 0:
+            assert np.abs(V).max() == 0
+            continue
+        check(V, ref, oracle.phase_grating(q, at, xyz, s, "f32"), 1e-5, f"potential {kw} s={s}")
+    pl.close()
+
+
+@pytest.mark.parametrize("kw", [dict(m=64, m3=4, nz=2), dict(m=64, m3=6, nz=3, tilt=True, beam_tilt=True, n3=2),
+                                dict(m=64, m3=3, nz=2, frPh=2, sub=3), dict(m=128, m3=16, nz=2, nat=200),
+                                dict(m=60, m3=4, nz=2), dict(m=64, m3=4, nz=2, mode=2)])
+def test_exit_wave(engine, oracle, kw):
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    pl = engine.plan(hp, at)
+    k = q.c.n3 - 1
+    j = 1 if q.c.frPh > 0 else 0
+    psi = pl.tap_wave(k, j)
+    ref = oracle.wave(q, at, k, j, prec="f64")
+    check(psi, ref, oracle.wave(q, at, k, j, prec="f32"), 1e-5 if q.c.m3 <= 16 else 1e-4, f"exit wave {kw}")
+    # intermediate depth
+    psi = pl.tap_wave(k, j, 1)
+    check(psi, oracle.wave(q, at, k, j, nslices=1, prec="f64"), None, 1e-5, f"wave after 1 slice {kw}")
+    pl.close()
+
+
+@pytest.mark.parametrize("name", list(S.GOLDEN_CASES))
+def test_images_against_golden_and_oracle(engine, oracle, name):
+    kw = S.GOLDEN_CASES[name]
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
+    out = engine.build_measurements(hp, at, want_potential=True, want_exitwave=True)
+    g = np.load(os.path.join(G, "tiny_cases.npz"))
+    check(out["image"], g[name + "_f64"], g[name + "_f32"], 1e-5, f"golden image {name}")
+    ref = oracle.build_measurements(hp, at, prec="f64", want_potential=True, want_exitwave=True)
+    check(out["image"], ref["image"], None, 1e-5, f"oracle image {name}")
+    check(out["exitwave"], ref["exitwave"], None, 1e-5, f"exit wave stack {name}")
+    check(out["potential"], ref["potential"], None, 1e-5, f"potential stack {name}")
+
+
+def test_dose_noise_statistics(engine, oracle):
+    """pixel_dose > 0: the Poisson surrogate rounds to whole counts, so float32 rounding can flip single
+    pixels; deviates are bit-identical (Philox), hence almost all pixels must agree to rounding."""
+    hp, at = S.case_tiny(m=64, m3=3, nz=2, pD=40.0)
+    hp.set(mtfa=1.0, mtfb=0.0, mtfc=0.0, mtfd=0.0)
+    fdes_amd.consistent(hp)
+    img = engine.build_measurements(hp, at)["image"]
+    ref = oracle.build_measurements(hp, at, prec="f32")["image"]
+    close = np.abs(img - ref) < 1e-4 * ref.max()
+    print("[parity] dose: fraction of pixels equal to rounding:", close.mean())
+    assert close.mean() > 0.98
+    assert abs(img.mean() - ref.mean()) < 2e-3 * ref.mean()
+
+
+def test_sharding_equals_single_plan(engine, oracle):
+    """Two 'ranks' (two plans on one GPU) run the block partition of (k, j); their partial intensity sums are
+    exchanged through fdes_plan_copy_intensity, summed (what the RCCL all-reduce does) and finalised by the
+    owner of k: equals the single-plan result (RNG keyed on (k, j), not on processing order)."""
+    import torch
+    from fdes_amd import shard
+    hp, at = S.case_tiny(m=64, m3=3, nz=2, frPh=3, n3=2, tilt=True)
+    fdes_amd.consistent(hp)
+    full = engine.build_measurements(hp, at)["image"]
+    world = 2
+    plans = [engine.plan(hp, at) for _ in range(world)]
+    bufs = [torch.zeros(64 * 64 * 2, device="cuda") for _ in range(world)]
+    torch.cuda.synchronize()
+
+    class Rank:
+        def __init__(self, r):
+            self.r, self.pl = r, plans[r]
+            self.begin_measurement = self.pl.begin_measurement
+            self.run_config = self.pl.run_config
+            self.end_measurement = self.pl.end_measurement
+
+    # ranks run one after the other; the "collective" is executed when the last rank arrives
+    pending = {}
+
+    def reduce_fn(rank_obj, k):
+        rank_obj.pl.copy_intensity(bufs[rank_obj.r].data_ptr(), 0)
+        pending.setdefault(k, []).append(rank_obj.r)
+
+    # phase 1: every rank computes its partial sums (end_measurement deferred): drive run_sharded per rank with a
+    # reduce hook that only snapshots; then sum and finalise on the owner.
+    own, ranks_of = shard.owners(2, 3, world)
+    w = 1.0 / 3.0
+    for k in range(2):
+        for r in range(world):
+            plans[r].begin_measurement(k)
+            for (kk, j) in shard.partition(2, 3, world, r):
+                if kk == k:
+                    plans[r].run_config(k, j, w)
+            plans[r].copy_intensity(bufs[r].data_ptr(), 0)
+        total = bufs[0] + bufs[1]
+        torch.cuda.synchronize()
+        plans[own[k]].copy_intensity(total.data_ptr(), 1)
+        plans[own[k]].end_measurement(k)
+    out = np.zeros_like(full)
+    for k in range(2):
+        out[k] = plans[own[k]].get_images()[k]
+    for pl in plans:
+        pl.close()
+    print("[parity] sharded vs single:", relerr(out, full.astype(np.float64)))
+    assert relerr(out, full.astype(np.float64)) < 1e-6
+
+
+def test_shipped_style_cnf_through_legacy_symbol(engine, oracle, tmp_path):
+    """The pyFDES.py call sequence: .cnf on disk + atoms as a flat [Z,x,y,z,DWF,occ] array -> FDES() -> buffer ==
+    Measurements.bin == oracle."""
+    hp, at = S.case_tiny(m=64, m3=3, nz=2, n3=2, tilt=True)
+    at.occ[:] = 1.0  # the legacy entry truncates occupancies to int (src/paramStructure.cu:323)
+    fdes_amd.consistent(hp)
+    cnf = tmp_path / "dataFDES.cnf"
+    fdes_amd.write_cnf(cnf, hp, None)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        out = np.zeros((hp.c.n3, hp.c.n2, hp.c.n1), np.float32)
+        fdes_amd.run_file(str(cnf), "Measurements.bin", "results.emd", atoms=at, out=out)
+        disk = np.fromfile("Measurements.bin", np.float32).reshape(out.shape)
+        assert os.path.exists("dataFDES_used.cnf")
+    finally:
+        os.chdir(cwd)
+    assert np.array_equal(out, disk)
+    hp2, _ = fdes_amd.read_cnf(cnf, skip_atoms=True)
+    ref = oracle.build_measurements(hp2, at, prec="f64")["image"]
+    check(out, ref, None, 1e-5, "legacy FDES() symbol")
+
+
+def test_full_size_propagation_properties(engine):
+    """BASELINE size (2048^2): size-independent properties of the propagation unit on device buffers:
+    linearity and band-limited norm conservation (t = 1)."""
+    import torch
+    hp, at = S.case_c3(k=2, m3=2, frPh=0)
+    fdes_amd.consistent(hp)
+    pl = engine.plan(hp, at)
+    m = 2048
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn(m, m, 2, device="cuda", generator=gen)
+    b = torch.randn(m, m, 2, device="cuda", generator=gen)
+    t = torch.zeros(m, m, 2, device="cuda")
+    t[..., 0] = 1.0
+    torch.cuda.synchronize()
+
+    def prop(x, n=1):
+        y = x.clone()
+        torch.cuda.synchronize()
+        for _ in range(n):
+            pl.propagate_dev(y.data_ptr(), t.data_ptr())
+        pl.sync()
+        return y
+
+    pa, pb, pab = prop(a), prop(b), prop(2.0 * a - 0.5 * b)
+    lin = (pab - (2.0 * pa - 0.5 * pb)).norm() / pab.norm()
+    print("[parity] 2048^2 linearity residual:", float(lin))
+    assert float(lin) < 5e-6
+    # after one step psi is band-limited; further steps with t = 1 conserve the norm
+    p2 = prop(pa, 4)
+    drift = abs(float(p2.norm() / pa.norm()) - 1.0)
+    print("[parity] 2048^2 norm drift over 4 free-space steps:", drift)
+    assert drift < 1e-5
+    pl.close()
