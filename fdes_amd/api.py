@@ -61,9 +61,11 @@ def read_cnf(path, bug_compatible=True, skip_atoms=False, capacity=1000):
         ts = np.ctypeslib.as_array(p.tiltspec, (2 * n3,)).copy()
         tb = np.ctypeslib.as_array(p.tiltbeam, (2 * n3,)).copy()
         df = np.ctypeslib.as_array(p.defoci, (n3,)).copy()
-        keep = (hp.c.tiltspec, hp.c.tiltbeam, hp.c.defoci, hp.c.cap)
         C.memmove(C.byref(hp.c), C.byref(p), C.sizeof(abi.Params))
-        hp.c.tiltspec, hp.c.tiltbeam, hp.c.defoci, hp.c.cap = keep
+        hp.c.cap = n3  # re-point the three arrays at the numpy-owned storage (p's are freed below)
+        hp.c.tiltspec = hp.tiltspec.ctypes.data_as(C.POINTER(C.c_float))
+        hp.c.tiltbeam = hp.tiltbeam.ctypes.data_as(C.POINTER(C.c_float))
+        hp.c.defoci = hp.defoci.ctypes.data_as(C.POINTER(C.c_float))
         hp.tiltspec[:] = ts
         hp.tiltbeam[:] = tb
         hp.defoci[:] = df

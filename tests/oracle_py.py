@@ -62,7 +62,22 @@ def lib():
         g("build_measurements").argtypes = [_P(Params), _P(Atoms), u32, R, R, R]
         g("build_measurements").restype = C.c_int
     _lib = L
+    # a 1-GPU box shares its host CPUs (16 per GPU): never let OpenMP spawn one thread per visible core
+    L.oracle_set_threads(default_threads())
     return L
+
+
+def default_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def _threads_for(npix):
+    """tiny grids: OpenMP fork/join costs more than the loops"""
+    lib().oracle_set_threads(1 if npix <= 128 * 128 else default_threads())
 
 
 def _dt(prec):
@@ -97,6 +112,7 @@ def fft2(f, inverse=False, prec="f32"):
     dt, ct, suf = _dt(prec)
     m2, m1 = f.shape
     buf = _c2buf(f, dt)
+    _threads_for(m1 * m2)
     getattr(lib(), f"oracle_fft2_{suf}")(_ptr(buf, ct), m1, m2, int(inverse))
     return _buf2c(buf)
 
@@ -149,6 +165,7 @@ def phase_grating(hp_sub, atoms, xyz, s, prec="f32"):
     zl = list_of_elements(atoms)
     zarr = (C.c_int * 103)(*zl)
     m1, m2 = hp_sub.c.m1, hp_sub.c.m2
+    _threads_for(m1 * m2)
     V = np.zeros((m2, m1, 2), dt)
     xyz = np.ascontiguousarray(xyz, np.float32)
     getattr(lib(), f"oracle_phase_grating_{suf}")(hp_sub.ptr, _ptr(xyz, C.c_float),
@@ -193,6 +210,7 @@ def wave(hp_sub, atoms, k, j, nslices=None, seed=1, prec="f32"):
     dt, ct, suf = _dt(prec)
     if nslices is None:
         nslices = hp_sub.c.m3
+    _threads_for(hp_sub.c.m1 * hp_sub.c.m2)
     a = np.zeros((hp_sub.c.m2, hp_sub.c.m1, 2), dt)
     getattr(lib(), f"oracle_wave_{suf}")(hp_sub.ptr, atoms.ptr, k, j, seed, nslices, _ptr(a, ct))
     return _buf2c(a)
@@ -202,6 +220,7 @@ def build_measurements(hp, atoms, seed=1, prec="f32", want_potential=False, want
     """hp: consistent params BEFORE sub-slicing. Returns dict(image[n3,n2,n1], ...)."""
     dt, ct, suf = _dt(prec)
     c = hp.c
+    _threads_for(c.m1 * c.m2)
     img = np.zeros((c.n3, c.n2, c.n1), dt)
     pot = np.zeros((c.m3, c.m2, c.m1, 2), dt) if want_potential else None
     ew = np.zeros((c.n3, c.m2, c.m1, 2), dt) if want_exitwave else None
