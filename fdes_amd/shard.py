@@ -7,6 +7,7 @@ global weight 1/count, the partial sums of a k that spans several ranks are sum-
 (`reduce_fn`, RCCL all-reduce in bench.py, gloo in the CPU tests), and the rank that owns k applies
 addNoiseAndMtf (:372).  RNG is keyed on (k, j), so results do not depend on the partition.
 """
+import numpy as np
 
 
 def partition(n3, count, world, rank):
@@ -36,7 +37,7 @@ def run_sharded(plan, n3, count, rank=0, world=1, reduce_fn=None):
     images this rank finalised."""
     mine = partition(n3, count, world, rank)
     own, ranks_of = owners(n3, count, world)
-    weight = 1.0 / float(count)
+    weight = float(np.float32(1.0) / np.float32(count))  # alpha of src/crystalMaker.cu:302-304 is a float32
     done = []
     by_k = {}
     for (k, j) in mine:

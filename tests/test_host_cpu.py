@@ -1,0 +1,256 @@
+"""CPU tests of the host side: C-ABI exports, parameter handling, the .cnf reader/writer and sharding."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import fdes_amd
+from fdes_amd import abi, shard
+from tests import specimens as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "fdes_abi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fdes_[a-z0-9_]+|FDES)\s*\(", hdr))
+    declared.discard("fdes_abi_h_")
+    lib = fdes_amd.load_library()
+    bound = {n for n, _, _ in abi.PROTOTYPES}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fdes_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    lib = fdes_amd.load_library()
+    if lib.fdes_gpu_available():
+        pytest.skip("GPU present")
+    with pytest.raises(fdes_amd.FdesError):
+        fdes_amd.Engine(0)
+
+
+def test_product_does_not_reference_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fdes_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle_py" not in txt and "liboracle" not in txt and "oracle/" not in txt, os.path.join(dirpath, f)
+
+
+def test_params_defaults_and_consistency(oracle):
+    lib = fdes_amd.load_library()
+    p = abi.Params()
+    assert lib.fdes_params_init(C.byref(p), 3) == 0
+    d = oracle.default_params(3)
+    for f in ("E0", "gamma", "lambda_", "sigma", "mtfa", "ObjAp", "m1", "m2", "m3", "d1", "d2", "d3", "subSlTh", "dn1",
+              "dn2", "n1", "n2", "n3", "frPh", "pD", "mode", "imPot"):
+        assert getattr(p, f) == getattr(d.c, f), f
+    assert p.ab.C1_0 == d.c.ab.C1_0 and p.ab.C3_0 == d.c.ab.C3_0
+    assert p.sample_name == b"Empty sample" and p.user_name == b"John Smith"
+    lib.fdes_params_release(C.byref(p))
+    for E0 in (40e3, 50e3, 200e3, 300e3):
+        a = fdes_amd.consistent(S.make_params(2, E0=E0, n1=10, dn1=3, n2=8, dn2=1, tiltbeam=[0, 0, 0, 2e-3]))
+        b = oracle.consistent(S.make_params(2, E0=E0, n1=10, dn1=3, n2=8, dn2=1, tiltbeam=[0, 0, 0, 2e-3]))
+        for f in ("gamma", "lambda_", "sigma", "m1", "m2", "doBeamTilt"):
+            assert getattr(a.c, f) == getattr(b.c, f)
+    hp = fdes_amd.consistent(S.make_params(1, E0=200e3))
+    assert (np.float32(hp.c.gamma), np.float32(hp.c.lambda_), np.float32(hp.c.sigma)) == \
+        (np.float32(1.3913902), np.float32(2.507934e-12), np.float32(7288400.5))  # src/paramStructure.cu:509-512
+
+
+def test_sub_slices_matches_reference_example():
+    # bin/dataFDES.cnf: 12 slices of 2.1 A, subpixel_size_z 0.2 A -> ratio 11, 132 sub-slices
+    hp = S.make_params(1, m3=12, d3=2.1e-10, subSlTh=0.2e-10)
+    q, ratio = fdes_amd.sub_sliced(hp)
+    assert ratio == 11 and q.c.m3 == 132 and abs(q.c.d3 - 2.1e-10 / 11) < 1e-17
+    q, ratio = fdes_amd.sub_sliced(S.make_params(1, m3=7, d3=1e-10, subSlTh=1e-10))
+    assert ratio == 1 and q.c.m3 == 7
+
+
+CNF = """# test file
+voltage:  80000     # comment
+C1:  -2e-9
+A1:  1e-9  0.5
+mtf_a: 0.58
+mtf_b: 0.42
+mode:  1
+gpu_number: 3
+sample_size_z:  5
+pixel_size_x:  0.2e-10
+pixel_size_y:  0.3e-10
+pixel_size_z:  1.5e-10
+border_size_x:  4
+border_size_y:  6
+image_size_x:  24
+image_size_y:  20
+image_size_z:  2
+frozen_phonons: 3
+pixel_dose: 12.5
+subpixel_size_z: 0.5e-10
+absorptive_potential_factor: 0.1
+specimen_tilt_offset_x: 0.17
+user_name:  Ada Lovelace
+sample_name:  Test sample
+specimen_tilt:  0.1  0.2
+specimen_tilt:  0.3  0.4
+beam_tilt:  1e-3  2e-3
+beam_tilt:  3e-3  4e-3
+defoci:  1e-9
+defoci:  2e-9
+atom: 79  1e-10  2e-10  3e-10  6e-21  1
+atom: 14  -1e-10  -2e-10  -3e-10  5e-21  0.5
+"""
+
+
+def _write(tmp_path, text):
+    p = tmp_path / "x.cnf"
+    p.write_text(text)
+    return p
+
+
+def test_read_cnf_clean_and_bug_compatible(tmp_path):
+    hp, at = fdes_amd.read_cnf(_write(tmp_path, CNF), bug_compatible=False)
+    c = hp.c
+    assert (c.E0, c.mode, c.m3, c.dn1, c.dn2, c.n1, c.n2, c.n3, c.frPh) == (80000.0, 1, 5, 4, 6, 24, 20, 2, 3)
+    assert (c.m1, c.m2) == (32, 32) and c.doBeamTilt == 1
+    assert np.float32(c.d1) == np.float32(0.2e-10) and np.float32(c.pD) == np.float32(12.5)
+    assert np.float32(c.ab.A1_0) == np.float32(1e-9) and np.float32(c.ab.A1_1) == np.float32(0.5)
+    assert c.user_name == b"Ada Lovelace" and c.sample_name == b"Test sample"
+    assert np.allclose(hp.tiltspec, [0.1, 0.2, 0.3, 0.4]) and np.allclose(hp.tiltbeam, [1e-3, 2e-3, 3e-3, 4e-3])
+    assert np.allclose(hp.defoci, [1e-9, 2e-9])
+    assert at.n == 2 and list(at.Z) == [79, 14] and np.allclose(at.xyz[1], [-1e-10, -2e-10, -3e-10])
+    assert np.float32(at.occ[1]) == np.float32(0.5)
+    # reference quirk: file ends in '\\n' after the last atom line -> that atom is read twice
+    hp, at = fdes_amd.read_cnf(_write(tmp_path, CNF), bug_compatible=True)
+    assert at.n == 3 and list(at.Z) == [79, 14, 14] and np.allclose(at.xyz[2], at.xyz[1])
+    # ... and not when the final newline is missing
+    hp, at = fdes_amd.read_cnf(_write(tmp_path, CNF.rstrip("\n")), bug_compatible=True)
+    assert at.n == 2
+    # quirk: a blank line after a specimen_tilt: line advances the index (stale token)
+    quirk = CNF.replace("specimen_tilt:  0.1  0.2\n", "specimen_tilt:  0.1  0.2\n\n").replace("image_size_z:  2", "image_size_z:  3")
+    hp, _ = fdes_amd.read_cnf(_write(tmp_path, quirk), bug_compatible=True)
+    assert np.allclose(hp.tiltspec[:6], [0.1, 0.2, 0.0, 0.0, 0.3, 0.4])
+    hp, _ = fdes_amd.read_cnf(_write(tmp_path, quirk), bug_compatible=False)
+    assert np.allclose(hp.tiltspec[:4], [0.1, 0.2, 0.3, 0.4])
+
+
+def test_default_subslice_thickness_is_not_the_parsed_d3(tmp_path):
+    # defaultParams sets subSlTh = the DEFAULT d3 (2 A) before parsing (src/paramStructure.cu:561)
+    txt = "\n".join(l for l in CNF.splitlines() if not l.startswith("subpixel_size_z")) + "\n"
+    hp, _ = fdes_amd.read_cnf(_write(tmp_path, txt))
+    assert np.float32(hp.c.subSlTh) == np.float32(2e-10)
+
+
+def test_cnf_write_read_round_trip(tmp_path):
+    hp, at = S.case_tiny(m=64, m3=3, nz=3, n3=2, tilt=True, beam_tilt=True, frPh=2, pD=3.0)
+    fdes_amd.consistent(hp)
+    p = tmp_path / "rt.cnf"
+    fdes_amd.write_cnf(p, hp, at)
+    hp2, at2 = fdes_amd.read_cnf(p, bug_compatible=False)
+    for f, _t in abi.Params._fields_:
+        if f in ("tiltspec", "tiltbeam", "defoci", "ab", "cap", "user_name", "institution", "department", "email",
+                 "comments", "sample_name", "material", "nAt"):
+            continue
+        a, b = getattr(hp.c, f), getattr(hp2.c, f)
+        assert a == b or abs(a - b) <= 1e-7 * abs(a), f
+    assert hp2.c.nAt == at.n
+    assert np.allclose(hp.tiltspec, hp2.tiltspec, rtol=1e-7) and np.allclose(hp.defoci, hp2.defoci, rtol=1e-7)
+    assert at2.n == at.n and np.array_equal(at.Z, at2.Z) and np.allclose(at.xyz, at2.xyz, rtol=1e-7)
+    # pointers of a parsed HostParams must reference its own numpy storage
+    assert C.cast(hp2.c.tiltspec, C.c_void_p).value == hp2.tiltspec.ctypes.data
+
+
+def test_atoms_from_array_truncates_occupancy_like_the_reference():
+    lib = fdes_amd.load_library()
+    arr = np.array([[79, 1, 2, 3, 6e-21, 0.7], [8, 4, 5, 6, 5e-21, 1.9]], np.float32)
+    a = abi.Atoms()
+    assert lib.fdes_atoms_from_array(C.byref(a), abi.fptr(arr), 2, 1) == 0
+    assert [a.occ[0], a.occ[1]] == [0.0, 1.0] and [a.Z[0], a.Z[1]] == [79, 8]  # (int) cast, src/paramStructure.cu:323
+    lib.fdes_atoms_release(C.byref(a))
+    assert lib.fdes_atoms_from_array(C.byref(a), abi.fptr(arr), 2, 0) == 0
+    assert np.float32(a.occ[0]) == np.float32(0.7)
+    lib.fdes_atoms_release(C.byref(a))
+
+
+def test_partition_covers_every_configuration_once():
+    for n3, count, world in [(1, 32, 8), (64, 8, 8), (3, 5, 4), (2, 3, 2), (1, 1, 4), (5, 1, 3)]:
+        seen = []
+        for r in range(world):
+            seen += shard.partition(n3, count, world, r)
+        assert seen == [(k, j) for k in range(n3) for j in range(count)]
+        own, ranks_of = shard.owners(n3, count, world)
+        assert set(own) == set(range(n3))
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from fdes_amd import shard
+from tests import oracle_py as O, specimens as S
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+hp, at = S.case_tiny(m=32, m3=2, nz=2, frPh=3, n3=2, tilt=True)
+O.consistent(hp)
+q, _ = O.sub_sliced(hp)
+m12 = q.c.m1 * q.c.m2
+
+class OraclePlan:  # stands in for fdes_amd.Plan: same driver calls, compute by the CPU oracle
+    def __init__(self):
+        self.I = np.zeros((q.c.m2, q.c.m1), np.complex128)
+        self.img = np.zeros((q.c.n3, q.c.n2, q.c.n1))
+    def begin_measurement(self, k):
+        self.I[:] = 0
+    def run_config(self, k, j, w):
+        import ctypes as C
+        psi = O.wave(q, at, k, j, prec="f64")
+        buf = O._c2buf(psi, np.float64)
+        O.lib().oracle_apply_lens_f64(q.ptr, k, buf.ctypes.data_as(C.POINTER(C.c_double)))
+        self.I += w * (buf[..., 0] ** 2 + buf[..., 1] ** 2)
+    def end_measurement(self, k):
+        import ctypes as C
+        buf = O._c2buf(self.I, np.float64)
+        J = np.zeros((q.c.n2, q.c.n1))
+        O.lib().oracle_add_noise_and_mtf_f64(q.ptr, k, buf.ctypes.data_as(C.POINTER(C.c_double)), J.ctypes.data_as(C.POINTER(C.c_double)))
+        self.img[k] = J
+
+def reduce_fn(plan, k):
+    t = torch.from_numpy(np.ascontiguousarray(plan.I.real))
+    dist.all_reduce(t)
+    plan.I = t.numpy().astype(np.complex128)
+
+pl = OraclePlan()
+done = shard.run_sharded(pl, q.c.n3, 3, rank, world, reduce_fn)
+full = O.build_measurements(hp, at, prec="f64")["image"]
+for k in done:
+    err = np.linalg.norm(pl.img[k] - full[k]) / np.linalg.norm(full[k])
+    assert err < 1e-12, (rank, k, err)
+out = torch.zeros(q.c.n3)
+for k in done:
+    out[k] = 1
+dist.all_reduce(out)
+assert bool((out == 1).all()), out  # every k finalised by exactly one rank
+dist.destroy_process_group()
+print("rank", rank, "ok", done)
+"""
+
+
+def test_sharded_driver_world_size_2_gloo(tmp_path):
+    """N > 1 path on CPU: two gloo ranks run shard.run_sharded with the oracle standing in for the GPU plan;
+    the reduced, finalised images equal the single-process result."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", str(script), ROOT], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
