@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--fft", type=int, default=0, help="engine option fft: 0 auto, 1 rocFFT, 2 hand-written")
     ap.add_argument("--probe-stride", type=int, default=8)
+    ap.add_argument("--lanes", type=int, default=2, help="configurations in flight per GPU (engine option lanes)")
+    ap.add_argument("--pass-threads", type=int, default=0)
     args = ap.parse_args()
 
     import numpy as np
@@ -54,7 +56,7 @@ def main():
     k_au = 30 if m >= 2048 else max(2, int(30 * m / 2048))
     hp, atoms = specimens.case_c3(k=k_au, n=m // 2, dn=m // 4, m3=args.slices, frPh=32)
     fdes_amd.consistent(hp)
-    eng = fdes_amd.Engine(local, fft=args.fft, probe_stride=args.probe_stride)
+    eng = fdes_amd.Engine(local, fft=args.fft, probe_stride=args.probe_stride, lanes=args.lanes, pass_threads=args.pass_threads)
     plan = eng.plan(hp, atoms)
     m3 = plan.m3
     weight = 1.0 / 32.0
@@ -114,10 +116,14 @@ def main():
             # one rocFFT 2-D C2C = 2 passes x (8 B read + 8 B write) per pixel ("FFT pass 16 B/px")
             kname, alg_bytes = f"rocFFT 2-D C2C {m}x{m} (row + column kernels)", 32.0 * px
         ach = alg_bytes / per_launch_s / 1e9
+        lanes = plan.lanes()
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
                 "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": int(fft_n),
-                "algorithmic_bytes_per_launch": alg_bytes}
+                "algorithmic_bytes_per_launch": alg_bytes,
+                # `lanes` configurations run on their own streams: kernels of different lanes share the chip, so a
+                # launch takes longer than it would alone while `lanes` of them progress at once
+                "concurrent_streams": lanes, "achieved_all_streams": round(ach * lanes, 1)}
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline:
         cpu = cpu_baseline(hp, atoms, m)
@@ -131,6 +137,7 @@ def main():
                                    f"1 frozen-phonon configuration per step per GPU (of 32), mode 0",
                        "wave": [m, m], "slices": m3, "atoms": atoms.n, "configs_per_step": world,
                        "parallelism": f"configs sharded over {world} GPU(s)"},
+            "lanes": plan.lanes(),
             "device_slice_loop_ms_per_slice": round(loop_ms / max(loop_slices, 1), 5),
             "full_step_algorithmic_GBps": round((176 + 56 * 1) * px * (loop_slices / max(loop_ms, 1e-9) * 1e3) / 1e9, 1),
             "slice_loop": "fused LDS passes" if fused else "rocFFT + point-wise kernels",

@@ -160,6 +160,7 @@ PROTOTYPES = [
     ("fdes_plan_get_images", C.c_int, [_vp, _P(C.c_float)]),
     ("fdes_plan_sync", C.c_int, [_vp]),
     ("fdes_plan_fft_backend", C.c_int, [_vp]),
+    ("fdes_plan_lanes", C.c_int, [_vp]),
     ("fdes_plan_num_slices", C.c_int, [_vp]),
     ("fdes_plan_slices_done", C.c_int64, [_vp]),
     ("fdes_plan_slice_loop_ms", C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
@@ -170,6 +171,7 @@ PROTOTYPES = [
     ("fdes_plan_tap_propagator", C.c_int, [_vp, _P(C.c_float)]),
     ("fdes_plan_propagate_dev", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
     ("fdes_fft2d_host", C.c_int, [_vp, _P(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("fdes_bench_pass", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P(C.c_double)]),
     ("fdes_set_option", C.c_int, [_vp, C.c_char_p, C.c_int64]),
     ("FDES", None, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, _P(C.c_float), C.c_int,
                     _P(C.c_float)]),

@@ -156,6 +156,11 @@ class Engine:
             raise FdesError(rc, self.err())
         return buf[..., 0] + 1j * buf[..., 1], rc
 
+    def bench_pass(self, n, pre, mid, post, store_t, iters=50, streams=1):
+        us = C.c_double()
+        _chk(self.lib.fdes_bench_pass(self.h, n, pre, mid, post, int(store_t), iters, streams, C.byref(us)), self.err())
+        return us.value
+
     def plan(self, hp, atoms):
         return Plan(self, hp, atoms)
 
@@ -231,6 +236,9 @@ class Plan:
 
     def fft_backend(self):
         return int(self.lib.fdes_plan_fft_backend(self.h))
+
+    def lanes(self):
+        return int(self.lib.fdes_plan_lanes(self.h))
 
     def slices_done(self):
         return int(self.lib.fdes_plan_slices_done(self.h))

@@ -9,6 +9,7 @@
 #include <rocfft/rocfft.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,9 @@ struct fdes_ctx {
     int opt_fft = 0;   // 0 auto, 1 rocFFT, 2 hand-written
     int opt_graph = 0;
     uint32_t seed = 1; // src/crystalMaker.cu:292
+    bool is_lane_ctx = false;
+    int lanes = 2;        // configurations in flight at once (own stream + buffers each) in the fused slice loop
+    int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
     std::map<std::pair<int, int>, Fft2D*> fft_cache; // plans are expensive to create: one per grid size
 };
@@ -65,6 +69,13 @@ struct fdes_plan {
     // fused LDS-pass slice loop (power-of-two grids): spectra in transposed ("T", [kx][y|ky]) and mixed
     // ("N", [y][kx]) layouts, tables in T layout
     bool fused = false;
+    int wg = 512;                       // threads per pass workgroup
+    std::vector<fdes_plan*> lanes;      // extra lanes (own context/stream/buffers); this plan is lane 0
+    std::vector<fdes_ctx*> lane_ctx;
+    std::vector<hipEvent_t> lane_ev;
+    bool is_lane = false;
+    unsigned rr = 0;                    // round-robin lane selector
+    bool lanes_dirty = false;           // lanes hold partial sums not yet folded into lane 0
     float2 *A = nullptr, *B = nullptr, *C = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
     float* GT = nullptr;
     std::vector<EvPair> probe;
@@ -216,8 +227,8 @@ int forward_propagation(fdes_plan* pl)
 //   P4  C[kx][y]       -FFT_y, band limit / m12, IFFT_y-> E[y][kx]
 //   P5  E, PSIH[y][kx] -IFFT_x both, t * psi, FFT_x->    F[kx][y]
 //   P6  F[kx][y]       -FFT_y, * P, IFFT_y->             PSIH[y][kx]
-PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; return a; }
-PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; return a; }
+PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; a.wg = pl->wg; return a; }
+PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; a.wg = pl->wg; return a; }
 
 int fused_potential_spectrum(fdes_plan* pl, const float* xyz, const BinGeom& g, int s)
 {
@@ -349,6 +360,30 @@ int exit_wave_post(fdes_plan* pl, int k, float weight)
     return FDES_OK;
 }
 
+// Lane 0 takes over the partial sums of the other lanes: I += I_lane (and the exit-wave sum), ordered by
+// events in both directions (lane stream -> lane 0 before the read, lane 0 -> lane stream before the lane
+// reuses its accumulators).
+int fold_lanes(fdes_plan* pl)
+{
+    fdes_ctx* c = pl->ctx;
+    if (!pl->lanes_dirty) return FDES_OK;
+    for (size_t l = 0; l < pl->lanes.size(); l++) {
+        fdes_plan* lp = pl->lanes[l];
+        HIPCHK(c, hipEventRecord(pl->lane_ev[l], lp->ctx->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, pl->lane_ev[l], 0));
+        HIPCHK(c, k_axpy(pl->I, lp->I, pl->m12, 1.f, c->stream));
+        HIPCHK(c, k_fill(lp->I, pl->m12, 0.f, 0.f, c->stream));
+        if (pl->want_ew) {
+            HIPCHK(c, k_axpy(pl->EW, lp->EW, pl->m12, 1.f, c->stream));
+            HIPCHK(c, k_fill(lp->EW, pl->m12, 0.f, 0.f, c->stream));
+        }
+        HIPCHK(c, hipEventRecord(pl->lane_ev[l], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(lp->ctx->stream, pl->lane_ev[l], 0));
+    }
+    pl->lanes_dirty = false;
+    return FDES_OK;
+}
+
 int check_params(fdes_ctx* ctx, const fdes_params* p, const fdes_atoms* a)
 {
     if (!p || !a || !p->tiltspec || !p->tiltbeam || !p->defoci) { ctx->err = "null parameter / atom pointers"; return FDES_EINVAL; }
@@ -408,6 +443,8 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "fft")) { if (value < 0 || value > 2) return FDES_EINVAL; c->opt_fft = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
+    if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 256 && value != 512) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "lanes")) { if (value < 1 || value > 4) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "probe_stride")) { c->probe_stride = (int)value; return FDES_OK; }
     return FDES_EINVAL;
 }
@@ -417,6 +454,10 @@ int fdes_plan_destroy(fdes_plan* pl)
     if (!pl) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     (void)hipSetDevice(c->device);
+    for (fdes_plan* l : pl->lanes) fdes_plan_destroy(l);
+    for (fdes_ctx* lc : pl->lane_ctx) fdes_destroy(lc);
+    for (hipEvent_t e : pl->lane_ev) (void)hipEventDestroy(e);
+    pl->lanes.clear();
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {pl->Z_d, pl->spec_d, pl->xyz0_d, pl->xyzTO_d, pl->xyzK_d, pl->xyzFP_d, pl->dwf_d, pl->occ_d, pl->bins.keys,
                     pl->bins.keys_sorted, pl->bins.vals, pl->bins.order, pl->bins.seg, pl->bins.tmp, pl->D, pl->VH, pl->T, pl->PSI,
@@ -528,6 +569,12 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLHIP(k_build_propagator(pl->P, pl->kp, 0, c->stream));
     pl->fused = pl->fft->backend == 2;
     if (pl->fused) {
+        const int m1 = pl->p.m1, m2 = pl->p.m2;
+        const bool ok256 = (m2 % lds_fft_rows_per_block(m1, 256) == 0) && (m1 % lds_fft_rows_per_block(m2, 256) == 0) &&
+                           lds_fft_rows_per_block(m1, 256) >= 4 && lds_fft_rows_per_block(m2, 256) >= 4; // >= 32-byte transposed segments
+        if (c->pass_threads == 256 && ok256) pl->wg = 256;
+        else if (c->pass_threads == 0 && c->lanes > 1 && ok256) pl->wg = 256;
+        else pl->wg = 512;
         PLCHK(dmalloc(c, &pl->A, pl->m12 * (size_t)pl->nZ));
         PLCHK(dmalloc(c, &pl->B, pl->m12));
         PLCHK(dmalloc(c, &pl->C, pl->m12));
@@ -543,6 +590,23 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLHIP(hipMemcpyAsync(pl->xyzTO_d, pl->xyz0_d, sizeof(float) * n3f, hipMemcpyDeviceToDevice, c->stream));
     PLCHK(tilt_coordinates(pl, pl->xyzTO_d, pl->p.tilt_offset_x, pl->p.tilt_offset_y, pl->p.tilt_offset_z));
     PLHIP(hipStreamSynchronize(c->stream));
+    if (pl->fused && c->lanes > 1 && !c->is_lane_ctx) {
+        for (int l = 1; l < c->lanes; l++) {
+            fdes_ctx* lc = nullptr;
+            PLCHK(fdes_create(&lc, c->device));
+            lc->is_lane_ctx = true;
+            lc->opt_fft = c->opt_fft; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes;
+            pl->lane_ctx.push_back(lc);
+            fdes_plan* lp = nullptr;
+            int lrc = fdes_plan_create(lc, p_in, a, &lp);
+            if (lrc != FDES_OK) { c->err = "lane plan: " + lc->err; fdes_plan_destroy(pl); return lrc; }
+            lp->is_lane = true;
+            pl->lanes.push_back(lp);
+            hipEvent_t ev;
+            PLHIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            pl->lane_ev.push_back(ev);
+        }
+    }
 #undef PLCHK
 #undef PLHIP
     *out = pl;
@@ -556,6 +620,7 @@ int fdes_plan_begin_measurement(fdes_plan* pl, int k)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, k_fill(pl->I, pl->m12, 0.f, 0.f, c->stream));
     if (pl->want_ew) HIPCHK(c, k_fill(pl->EW, pl->m12, 0.f, 0.f, c->stream));
+    for (fdes_plan* l : pl->lanes) { l->want_ew = pl->want_ew; RC(fdes_plan_begin_measurement(l, k)); }
     return ensure_tilt(pl, k);
 }
 
@@ -564,6 +629,15 @@ int fdes_plan_run_config(fdes_plan* pl, int k, int j, float weight)
     if (!pl || k < 0 || k >= pl->p.n3 || j < 0) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
+    if (!pl->lanes.empty()) {
+        const unsigned lane = pl->rr++ % (unsigned)(pl->lanes.size() + 1);
+        if (lane > 0) {
+            pl->lanes_dirty = true;
+            int rcl = fdes_plan_run_config(pl->lanes[lane - 1], k, j, weight);
+            if (rcl != FDES_OK) c->err = "lane: " + pl->lanes[lane - 1]->ctx->err;
+            return rcl;
+        }
+    }
     RC(incoming_wave(pl, k));
     RC(config_atoms(pl, k, j));
     if (pl->ev_used == pl->evs.size()) {
@@ -589,6 +663,7 @@ int fdes_plan_end_measurement(fdes_plan* pl, int k)
     const fdes_params& p = pl->p;
     HIPCHK(c, hipSetDevice(c->device));
     const float alpha = 1.f / ((float)(p.m1 * p.m2));
+    RC(fold_lanes(pl));
     HIPCHK(c, fft_exec(pl,pl->I, false, c->stream));
     if (fabsf(p.illangle) > FLT_EPSILON) {
         if (p.mode == 0) HIPCHK(c, k_spatial_incoherence(pl->I, pl->kp, p.defoci[k], 0, c->stream));
@@ -619,6 +694,7 @@ int fdes_plan_copy_intensity(fdes_plan* pl, void* dev_buf, int to_plan)
     if (!pl || !dev_buf) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
+    RC(fold_lanes(pl));
     if (to_plan) HIPCHK(c, hipMemcpyAsync(pl->I, dev_buf, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
     else HIPCHK(c, hipMemcpyAsync(dev_buf, pl->I, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -637,6 +713,7 @@ int fdes_plan_sync(fdes_plan* pl)
 {
     if (!pl) return FDES_EINVAL;
     HIPCHK(pl->ctx, hipSetDevice(pl->ctx->device));
+    for (fdes_plan* l : pl->lanes) HIPCHK(pl->ctx, hipStreamSynchronize(l->ctx->stream));
     HIPCHK(pl->ctx, hipStreamSynchronize(pl->ctx->stream));
     return FDES_OK;
 }
@@ -652,8 +729,15 @@ int fdes_plan_get_images(fdes_plan* pl, float* image)
 }
 
 int fdes_plan_fft_backend(const fdes_plan* pl) { return pl ? pl->fft->backend : FDES_EINVAL; }
+int fdes_plan_lanes(const fdes_plan* pl) { return pl ? (int)pl->lanes.size() + 1 : FDES_EINVAL; }
 int fdes_plan_num_slices(const fdes_plan* pl) { return pl ? pl->p.m3 : FDES_EINVAL; }
-int64_t fdes_plan_slices_done(const fdes_plan* pl) { return pl ? pl->slices_done : 0; }
+int64_t fdes_plan_slices_done(const fdes_plan* pl)
+{
+    if (!pl) return 0;
+    int64_t n = pl->slices_done;
+    for (const fdes_plan* l : pl->lanes) n += l->slices_done;
+    return n;
+}
 
 int fdes_plan_slice_loop_ms(fdes_plan* pl, double* total_ms, int64_t* slices)
 {
@@ -670,6 +754,13 @@ int fdes_plan_slice_loop_ms(fdes_plan* pl, double* total_ms, int64_t* slices)
         n += pl->evs[i].slices;
     }
     pl->ev_used = 0;
+    for (fdes_plan* l : pl->lanes) {
+        double tl = 0;
+        int64_t nl = 0;
+        RC(fdes_plan_slice_loop_ms(l, &tl, &nl));
+        t += tl;
+        n += nl;
+    }
     if (total_ms) *total_ms = t;
     if (slices) *slices = n;
     return FDES_OK;
@@ -687,9 +778,17 @@ int fdes_plan_probe_ms(fdes_plan* pl, double* total_ms, int64_t* launches)
         HIPCHK(c, hipEventElapsedTime(&ms, pl->probe[i].a, pl->probe[i].b));
         t += ms;
     }
-    if (total_ms) *total_ms = t;
-    if (launches) *launches = (int64_t)pl->probe_used;
+    int64_t nl = (int64_t)pl->probe_used;
     pl->probe_used = 0;
+    for (fdes_plan* l : pl->lanes) {
+        double tl = 0;
+        int64_t ll = 0;
+        RC(fdes_plan_probe_ms(l, &tl, &ll));
+        t += tl;
+        nl += ll;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = nl;
     return FDES_OK;
 }
 
@@ -792,6 +891,56 @@ int fdes_fft2d_host(fdes_ctx* c, float* data, int m1, int m2, int inverse, int b
     return used; // 1 = rocFFT, 2 = LDS kernels
 }
 
+// Times one LDS row pass on scratch n x n grids (micro-benchmark hook): mean time per launch in us.
+// streams > 1 issues the launches round-robin on that many HIP streams, each with its own grids
+// (do concurrent kernels overlap their memory and compute phases?).
+int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t, int iters, int streams, double* us)
+{
+    if (!c || !us || iters < 1 || streams < 1 || streams > 8 || !lds_fft_supported_len(n)) return FDES_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    Fft2D f;
+    std::string ferr;
+    if (f.create(n, n, 2, c->stream, &ferr) != 0) { f.destroy(); c->err = ferr; return FDES_EGPU; }
+    const size_t m12 = (size_t)n * n;
+    std::vector<void*> bufs;
+    std::vector<hipStream_t> sts;
+    std::vector<PassArgs> args;
+    int rc = FDES_OK;
+    for (int q = 0; q < streams && rc == FDES_OK; q++) {
+        float2 *a = nullptr, *b = nullptr, *o = nullptr, *pt = nullptr;
+        float* g = nullptr;
+        hipStream_t st = nullptr;
+        if (hipMalloc((void**)&a, 8 * m12) != hipSuccess || hipMalloc((void**)&b, 8 * m12) != hipSuccess || hipMalloc((void**)&o, 8 * m12) != hipSuccess ||
+            hipMalloc((void**)&pt, 8 * m12) != hipSuccess || hipMalloc((void**)&g, 4 * m12) != hipSuccess ||
+            hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rc = FDES_ENOMEM; }
+        bufs.insert(bufs.end(), {a, b, o, pt, g});
+        if (st) sts.push_back(st);
+        if (rc != FDES_OK) break;
+        (void)hipMemset(a, 0, 8 * m12); (void)hipMemset(b, 0, 8 * m12); (void)hipMemset(pt, 0, 8 * m12); (void)hipMemset(g, 0, 4 * m12);
+        PassArgs A;
+        A.in0 = a; A.in1 = b; A.out = o; A.zsrc = a; A.gtab = g; A.ptab = pt; A.tw0 = f.tw0x; A.tw1 = f.tw1x; A.nrows = n;
+        A.nspecies = 1; A.species_stride = m12; A.scale = 1.f; A.mindim = n;
+        A.wg = c->pass_threads == 256 ? 256 : 512;
+        args.push_back(A);
+    }
+    if (rc == FDES_OK) {
+        hipError_t e = hipSuccess;
+        for (int q = 0; q < streams && e == hipSuccess; q++) e = lds_pass(n, pre, mid, post, store_t != 0, args[q], sts[q]);
+        (void)hipDeviceSynchronize();
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters && e == hipSuccess; i++)
+            for (int q = 0; q < streams && e == hipSuccess; q++) e = lds_pass(n, pre, mid, post, store_t != 0, args[q], sts[q]);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        auto t1 = std::chrono::steady_clock::now();
+        if (e == hipSuccess) *us = std::chrono::duration<double, std::micro>(t1 - t0).count() / ((double)iters * streams);
+        else { c->err = std::string("bench_pass: ") + hipGetErrorString(e); rc = FDES_EGPU; }
+    }
+    for (void* q : bufs) if (q) (void)hipFree(q);
+    for (hipStream_t st : sts) (void)hipStreamDestroy(st);
+    f.destroy();
+    return rc;
+}
+
 // ------------------------------- buildMeasurements ---------------------------------------------
 
 int fdes_build_measurements(fdes_ctx* c, const fdes_params* p, const fdes_atoms* a, float* image, float* potential, float* exitwave)
@@ -806,6 +955,7 @@ int fdes_build_measurements(fdes_ctx* c, const fdes_params* p, const fdes_atoms*
     for (int k = 0; k < pl->p.n3 && rc == FDES_OK; k++) {
         rc = fdes_plan_begin_measurement(pl, k);
         for (int j = 0; j < count && rc == FDES_OK; j++) rc = fdes_plan_run_config(pl, k, j, alpha);
+        if (rc == FDES_OK && exitwave) rc = fold_lanes(pl);
         if (rc == FDES_OK && exitwave) {
             hipError_t e = hipMemcpyAsync(exitwave + 2 * pl->m12 * (size_t)k, pl->EW, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

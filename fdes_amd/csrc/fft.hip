@@ -12,7 +12,7 @@ namespace fdes {
 bool Fft2D::lds_supported(int m1, int m2)
 {
     if (!lds_fft_supported_len(m1) || !lds_fft_supported_len(m2)) return false;
-    return (m2 % lds_fft_rows_per_block(m1) == 0) && (m1 % lds_fft_rows_per_block(m2) == 0);
+    return (m2 % lds_fft_rows_per_block(m1, 512) == 0) && (m1 % lds_fft_rows_per_block(m2, 512) == 0);
 }
 
 static int upload_twiddles(int n, float2** tw0, float2** tw1, std::string* err)

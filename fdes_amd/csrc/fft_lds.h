@@ -38,12 +38,13 @@ struct PassArgs {
     size_t species_stride = 0;   // elements between species grids (in0 and gtab)
     float scale = 1.f;
     int mindim = 0;              // min(m1, m2) for the band limit
+    int wg = 512;                // threads per workgroup (512 or 256)
 };
 
 // Row lengths the kernels are instantiated for.
 bool lds_fft_supported_len(int n);
-// rows per workgroup for row length n
-int lds_fft_rows_per_block(int n);
+// rows per workgroup for row length n and wg threads per workgroup (512: one workgroup per CU; 256: two)
+int lds_fft_rows_per_block(int n, int wg);
 // fills host arrays (float2 as 2 floats) with the twiddle tables of length n: tw0[16*T], tw1[T]
 void lds_fft_twiddles(int n, float* tw0, float* tw1);
 

@@ -139,25 +139,55 @@ __device__ __forceinline__ int padi(int i) { return i + (i >> 4); }
 __device__ __forceinline__ int iwc(int i, int m) { return (i > m / 2) ? i - m : i; } // iwCoordIp
 
 constexpr int NR = 2;        // rows per thread (twiddles are shared between them)
-constexpr int WG = 512;      // threads per workgroup: 8 waves = 2 per SIMD -> 256 VGPRs per lane
 
-template <int N> struct Geo {
+// WG threads per workgroup (512: one workgroup per CU; 256: two per CU, 2 waves per SIMD either way ->
+// 256 VGPRs per lane), each thread owning NR rows x 16 elements.
+template <int N, int WG> struct Geo {
     static constexpr int T = N / 16;                 // threads per row
-    static constexpr int R = 16384 / N;              // rows per workgroup
+    static constexpr int R = WG * NR * 16 / N;       // rows per workgroup
     static constexpr int RH = R / NR;                // rows per "half": thread (r, t) owns rows r and r + RH
     static constexpr int R3 = N / 256;               // radix of the last stage
     static constexpr int G = (R3 >= 1) ? 16 / R3 : 16;
     static constexpr int LDROW = N + N / 16;         // padded row length in float2
-    static constexpr int SH = (R >= 16) ? 0 : ((R == 8) ? 1 : 2); // transposed-tile swizzle shift
+    static constexpr int SH = (R >= 16) ? 0 : ((R == 8) ? 1 : ((R == 4) ? 2 : 3)); // transposed-tile swizzle shift
 };
 
-// NR row FFTs at once, data in a[h][16] (a[h][l] = x_h[t + T l] on entry, X_h[t + T l] on exit).
-template <int N, bool INV, bool WAR0>
-__device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict__ lds, const int r, const int t,
-                                        const float2* __restrict__ tw0, const float2* __restrict__ tw1)
+// Synchronisation among the waves that share a row (T/64 of them; a row pair never leaves its waves):
+// rows of <= 1024 points live in ONE wave, whose LDS instructions execute in order, so a compiler fence
+// suffices; longer rows use a counting barrier on an LDS word private to the group.  Unlike
+// __syncthreads() this lets the row groups of a workgroup drift apart: one group transforms while
+// another still waits for its global loads.
+// Measured (2048^2, MI355X): the counting barrier is correct but not faster than s_barrier (the row groups of
+// a workgroup contend for the same LDS/VALU) and costs registers; concurrency comes from a second stream.
+constexpr bool kGroupSpin = false;
+struct GroupSync {
+    unsigned* cnt;   // LDS counter of this wave group
+    unsigned expect; // arrivals expected so far
+};
+template <int NW> __device__ __forceinline__ void group_sync(GroupSync& g)
 {
-    using G_ = Geo<N>;
+    if constexpr (NW <= 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        asm volatile("" ::: "memory");
+    } else if constexpr (!kGroupSpin) {
+        __syncthreads();
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's LDS writes have landed
+        if ((threadIdx.x & 63) == 0) atomicAdd(g.cnt, 1u);
+        g.expect += NW;
+        while ((int)(*(volatile unsigned*)g.cnt - g.expect) < 0) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    }
+}
+
+// NR row FFTs at once, data in a[h][16] (a[h][l] = x_h[t + T l] on entry, X_h[t + T l] on exit).
+template <int N, int WG, bool INV, bool WAR0>
+__device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict__ lds, const int r, const int t,
+                                        const float2* __restrict__ tw0, const float2* __restrict__ tw1, GroupSync& gs)
+{
+    using G_ = Geo<N, WG>;
     constexpr int T = G_::T;
+    constexpr int NW = (T + 63) / 64;
     // ---- stage 0
 #pragma unroll
     for (int h = 0; h < NR; h++) r16<INV>(a[h]);
@@ -167,14 +197,14 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
 #pragma unroll
         for (int h = 0; h < NR; h++) a[h][k] = twmul<INV>(a[h][k], w);
     }
-    if (WAR0) __syncthreads();
+    if (WAR0) group_sync<NW>(gs);
 #pragma unroll
     for (int h = 0; h < NR; h++) {
         float2* row = lds + (r + h * G_::RH) * G_::LDROW;
 #pragma unroll
         for (int k = 0; k < 16; k++) row[padi(16 * t + k)] = a[h][k];
     }
-    __syncthreads();
+    group_sync<NW>(gs);
 #pragma unroll
     for (int h = 0; h < NR; h++) {
         const float2* row = lds + (r + h * G_::RH) * G_::LDROW;
@@ -192,14 +222,14 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
 #pragma unroll
             for (int h = 0; h < NR; h++) a[h][k] = twmul<INV>(a[h][k], w);
         }
-        __syncthreads();
+        group_sync<NW>(gs);
 #pragma unroll
         for (int h = 0; h < NR; h++) {
             float2* row = lds + (r + h * G_::RH) * G_::LDROW;
 #pragma unroll
             for (int k = 0; k < 16; k++) row[padi(q + 256 * p + 16 * k)] = a[h][k];
         }
-        __syncthreads();
+        group_sync<NW>(gs);
 #pragma unroll
         for (int h = 0; h < NR; h++) {
             const float2* row = lds + (r + h * G_::RH) * G_::LDROW;
@@ -226,28 +256,40 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
     }
 }
 
-template <int N, int XF, bool WAR0>
-__device__ __forceinline__ void xform(float2 (&a)[NR][16], float2* lds, int r, int t, const float2* tw0, const float2* tw1)
+template <int N, int WG, int XF, bool WAR0>
+__device__ __forceinline__ void xform(float2 (&a)[NR][16], float2* lds, int r, int t, const float2* tw0, const float2* tw1,
+                                      GroupSync& gs)
 {
-    if constexpr (XF == XF_FWD) row_fft<N, false, WAR0>(a, lds, r, t, tw0, tw1);
-    if constexpr (XF == XF_INV) row_fft<N, true, WAR0>(a, lds, r, t, tw0, tw1);
+    if constexpr (XF == XF_FWD) row_fft<N, WG, false, WAR0>(a, lds, r, t, tw0, tw1, gs);
+    if constexpr (XF == XF_INV) row_fft<N, WG, true, WAR0>(a, lds, r, t, tw0, tw1, gs);
 }
 
-template <int N, int PRE, int MID, int POST, bool STORE_T>
+template <int N, int WG, int PRE, int MID, int POST, bool STORE_T>
 __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
 {
-    using G_ = Geo<N>;
+    using G_ = Geo<N, WG>;
     constexpr int T = G_::T, R = G_::R, RH = G_::RH;
     extern __shared__ float2 lds[];
+    const float2* __restrict__ tw0 = A.tw0;
+    const float2* __restrict__ tw1 = A.tw1;
+    // per-group barrier words live behind the row buffers
+    constexpr int NWG = (T + 63) / 64;
+    unsigned* cnts = reinterpret_cast<unsigned*>(lds + (size_t)G_::LDROW * R);
+    GroupSync gs;
+    gs.cnt = cnts + (NWG > 1 ? threadIdx.x / (64 * NWG) : 0);
+    gs.expect = 0;
+    if constexpr (NWG > 1) {
+        if (threadIdx.x < WG / 64) cnts[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    // (Measured and dropped: letting a workgroup walk several row groups so that a 256-thread kernel leaves one
+    // LDS slot per CU to another stream's kernel was slower than plain one-group workgroups on two streams.)
     const int tid = threadIdx.x;
     const int r = tid / T, t = tid % T;
     // XCD-aware remap: blocks with equal blockIdx % 8 share an XCD; give them consecutive row groups
-    int bg = blockIdx.x;
-    const int nb = gridDim.x;
-    if ((nb & 7) == 0) bg = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+    int bg = (int)blockIdx.x;
+    if ((gridDim.x & 7) == 0) bg = (bg & 7) * ((int)gridDim.x >> 3) + (bg >> 3);
     const int row0 = bg * R;
-    const float2* __restrict__ tw0 = A.tw0;
-    const float2* __restrict__ tw1 = A.tw1;
     size_t rbase[NR];
     int grow[NR];
 #pragma unroll
@@ -270,7 +312,7 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
             for (int h = 0; h < NR; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = A.in0[zo + rbase[h] + t + T * l];
-            xform<N, PRE, true>(a, lds, r, t, tw0, tw1);
+            xform<N, WG, PRE, true>(a, lds, r, t, tw0, tw1, gs);
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
@@ -295,7 +337,7 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
 #pragma unroll
                 for (int l = 0; l < 16; l++) A.zsrc[rbase[h] + t + T * l] = make_float2(0.f, 0.f);
         }
-        xform<N, PRE, false>(a, lds, r, t, tw0, tw1);
+        xform<N, WG, PRE, false>(a, lds, r, t, tw0, tw1, gs);
         if constexpr (MID == MID_EXPIV) {
 #pragma unroll
             for (int h = 0; h < NR; h++)
@@ -342,14 +384,14 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
             for (int h = 0; h < NR; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) b[h][l] = A.in1[rbase[h] + t + T * l];
-            xform<N, PRE, true>(b, lds, r, t, tw0, tw1);
+            xform<N, WG, PRE, true>(b, lds, r, t, tw0, tw1, gs);
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], b[h][l]); // f0 = t, f1 = psi
         }
     }
-    xform<N, POST, (PRE != XF_NONE)>(a, lds, r, t, tw0, tw1);
+    xform<N, WG, POST, (PRE != XF_NONE)>(a, lds, r, t, tw0, tw1, gs);
 
     if constexpr (!STORE_T) {
 #pragma unroll
@@ -372,7 +414,7 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
         float2* __restrict__ dst = A.out;
         const int ld = A.nrows; // transposed grid: N rows of length nrows
 #pragma unroll
-        for (int it = 0; it < 16384 / WG; it++) {
+        for (int it = 0; it < NR * 16; it++) {
             const int e = it * WG + tid;
             const int rr = e & (R - 1), c = e / R;
             dst[(size_t)c * ld + row0 + rr] = lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))];
@@ -380,12 +422,12 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
     }
 }
 
-template <int N, int PRE, int MID, int POST, bool ST> hipError_t launch(const PassArgs& a, hipStream_t st)
+template <int N, int WG, int PRE, int MID, int POST, bool ST> hipError_t launch(const PassArgs& a, hipStream_t st)
 {
-    using G_ = Geo<N>;
+    using G_ = Geo<N, WG>;
     static bool attr_set = false;
-    constexpr size_t lds_bytes = sizeof(float2) * (size_t)G_::LDROW * G_::R;
-    auto kern = k_pass<N, PRE, MID, POST, ST>;
+    constexpr size_t lds_bytes = sizeof(float2) * (size_t)G_::LDROW * G_::R + 64;
+    auto kern = k_pass<N, WG, PRE, MID, POST, ST>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -396,16 +438,16 @@ template <int N, int PRE, int MID, int POST, bool ST> hipError_t launch(const Pa
     return hipGetLastError();
 }
 
-template <int N> hipError_t dispatch(int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
+template <int N, int WG> hipError_t dispatch(int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
 {
-#define CASE(P, M, Q, S) if (pre == P && mid == M && post == Q && st_t == S) return launch<N, P, M, Q, S>(a, st);
+#define CASE(P, M, Q, S) if (pre == P && mid == M && post == Q && st_t == S) return launch<N, WG, P, M, Q, S>(a, st);
+    CASE(XF_NONE, MID_NONE, XF_NONE, false)  // copy (memory floor of the access pattern; micro-benchmark)
+    CASE(XF_NONE, MID_NONE, XF_NONE, true)   // transpose-copy
     CASE(XF_FWD, MID_NONE, XF_NONE, false)   // real -> mixed, natural store            (start of a configuration)
     CASE(XF_INV, MID_NONE, XF_NONE, false)   // mixed -> real, natural store            (end of a configuration)
     CASE(XF_INV, MID_SCALE, XF_NONE, false)
     CASE(XF_FWD, MID_NONE, XF_NONE, true)    // generic 2-D FFT passes
     CASE(XF_INV, MID_NONE, XF_NONE, true)
-    CASE(XF_FWD, MID_SCALE, XF_NONE, true)
-    CASE(XF_INV, MID_SCALE, XF_NONE, true)
     CASE(XF_FWD, MID_ZSRC, XF_NONE, true)    // P1: deposit grid -> x spectrum
     CASE(XF_FWD, MID_GTAB, XF_INV, true)     // P2: y FFT * f_e/sinc, y IFFT (one species)
     CASE(XF_FWD, MID_GTABN, XF_INV, true)    // P2: y FFT * f_e/sinc, species sum, y IFFT
@@ -417,10 +459,16 @@ template <int N> hipError_t dispatch(int pre, int mid, int post, bool st_t, cons
     return hipErrorInvalidValue;
 }
 
+template <int N> hipError_t dispatch_wg(int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
+{
+    if (a.wg == 256) return dispatch<N, 256>(pre, mid, post, st_t, a, st);
+    return dispatch<N, 512>(pre, mid, post, st_t, a, st);
+}
+
 } // namespace
 
 bool lds_fft_supported_len(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
-int lds_fft_rows_per_block(int n) { return 16384 / n; }
+int lds_fft_rows_per_block(int n, int wg) { return (wg == 256 ? 256 : 512) * NR * 16 / n; }
 
 void lds_fft_twiddles(int n, float* tw0, float* tw1)
 {
@@ -444,11 +492,11 @@ void lds_fft_twiddles(int n, float* tw0, float* tw1)
 hipError_t lds_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
 {
     switch (n) {
-    case 256: return dispatch<256>(pre, mid, post, st_t, a, st);
-    case 512: return dispatch<512>(pre, mid, post, st_t, a, st);
-    case 1024: return dispatch<1024>(pre, mid, post, st_t, a, st);
-    case 2048: return dispatch<2048>(pre, mid, post, st_t, a, st);
-    case 4096: return dispatch<4096>(pre, mid, post, st_t, a, st);
+    case 256: return dispatch_wg<256>(pre, mid, post, st_t, a, st);
+    case 512: return dispatch_wg<512>(pre, mid, post, st_t, a, st);
+    case 1024: return dispatch_wg<1024>(pre, mid, post, st_t, a, st);
+    case 2048: return dispatch_wg<2048>(pre, mid, post, st_t, a, st);
+    case 4096: return dispatch_wg<4096>(pre, mid, post, st_t, a, st);
     default: return hipErrorInvalidValue;
     }
 }

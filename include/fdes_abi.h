@@ -154,6 +154,8 @@ int fdes_plan_get_images(fdes_plan* plan, float* image);
 int fdes_plan_sync(fdes_plan* plan);
 /* 1: generic slice loop on rocFFT + point-wise kernels; 2: fused LDS-pass slice loop. */
 int fdes_plan_fft_backend(const fdes_plan* plan);
+/* Configurations the plan keeps in flight at once (lanes: own HIP stream and buffers each; option "lanes"). */
+int fdes_plan_lanes(const fdes_plan* plan);
 /* Number of (sub-)slices m3 after sub-slicing; slice-propagations done so far. */
 int fdes_plan_num_slices(const fdes_plan* plan);
 int64_t fdes_plan_slices_done(const fdes_plan* plan);
@@ -188,11 +190,19 @@ int fdes_plan_propagate_dev(fdes_plan* plan, void* psi_dev, const void* t_dev, i
  * Returns the back-end used (1 or 2) or a negative error. */
 int fdes_fft2d_host(fdes_ctx* ctx, float* data, int m1, int m2, int inverse, int backend);
 
+/* Micro-benchmark of one LDS row pass on zero-filled n x n scratch grids: mean launch time [us].
+ * pre/post: 0 none, 1 forward, 2 inverse row FFT; mid: point-wise op id (fft_lds.h); store_t: transposed store;
+ * streams: launches are issued round-robin on this many HIP streams (own grids each), host-timed. */
+int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_t, int iters, int streams, double* us);
+
 /* Engine options (before fdes_plan_create).  Unknown keys -> FDES_EINVAL.
  *   "fft"        0 = auto, 1 = rocFFT, 2 = hand-written LDS FFT kernels (power-of-two grids)
  *   "graph"      1 = replay the slice loop from a hipGraph
  *   "seed"       frozen-phonon seed (reference: 1, src/crystalMaker.cu:292)
- *   "probe_stride"  see fdes_plan_probe_ms                                                  */
+ *   "probe_stride"  see fdes_plan_probe_ms
+ *   "lanes"      1..4 configurations in flight at once in the fused slice loop (default 2): run_config calls are
+ *                dealt round-robin to lanes, partial intensity sums are folded in end_measurement
+ *   "pass_threads"  0 auto, 256 or 512 threads per LDS-pass workgroup                        */
 int fdes_set_option(fdes_ctx* ctx, const char* key, int64_t value);
 
 /* ---------------- legacy symbol ---------------- */
