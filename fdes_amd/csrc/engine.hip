@@ -177,7 +177,7 @@ int config_atoms(fdes_plan* pl, int k, int j)
     else
         HIPCHK(c, hipMemcpyAsync(pl->xyzFP_d, pl->xyzK_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, c->stream));
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
-    HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->nAt, g, pl->bins, c->stream));
+    HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, pl->fused, c->stream));
     return FDES_OK;
 }
 
@@ -230,15 +230,20 @@ int forward_propagation(fdes_plan* pl)
 PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; a.wg = pl->wg; return a; }
 PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; a.wg = pl->wg; return a; }
 
-int fused_potential_spectrum(fdes_plan* pl, const float* xyz, const BinGeom& g, int s)
+// Potential of the slice PAIR (s0, s0 + 1), s0 even: W = V_s0 + i V_(s0+1) (the deposits are real and the filter
+// G is real and even, so one complex transform carries two slices).  P1' builds the x-spectra of the deposit rows
+// straight from the sorted atom records (no deposit grid), P2 applies the filter in (kx, ky) and sums the species.
+int fused_potential_pair(fdes_plan* pl, int s0)
 {
     fdes_ctx* c = pl->ctx;
     const int m1 = pl->p.m1, m2 = pl->p.m2;
     for (int z = 0; z < pl->nZ; z++) {
-        HIPCHK(c, geom_deposit(pl->D, xyz, pl->occ_d, pl->bins, s * pl->nZ + z, g, pl->p.imPot, pl->deposit_blocks, c->stream));
         PassArgs a = pass_x(pl);
-        a.in0 = pl->D; a.zsrc = pl->D; a.out = pl->A + (size_t)z * pl->m12;
-        HIPCHK(c, lds_pass(m1, XF_FWD, MID_ZSRC, XF_NONE, true, a, c->stream));
+        a.out = pl->A + (size_t)z * pl->m12;
+        a.recs = pl->bins.recs_sorted; a.rowstart = pl->bins.rowstart;
+        a.q0 = s0 * pl->nZ + z;
+        a.q1 = (s0 + 1 < pl->p.m3) ? (s0 + 1) * pl->nZ + z : -1;
+        HIPCHK(c, lds_pass(m1, XF_FWD, MID_ATOMS, XF_NONE, true, a, c->stream));
     }
     PassArgs b = pass_y(pl);
     b.in0 = pl->A; b.gtab = pl->GT; b.out = pl->B; b.nspecies = pl->nZ; b.species_stride = pl->m12;
@@ -246,14 +251,14 @@ int fused_potential_spectrum(fdes_plan* pl, const float* xyz, const BinGeom& g, 
     return FDES_OK;
 }
 
-int fused_slice(fdes_plan* pl, const float* xyz, const BinGeom& g, int s)
+int fused_slice(fdes_plan* pl, int s)
 {
     fdes_ctx* c = pl->ctx;
     const int m1 = pl->p.m1, m2 = pl->p.m2;
-    RC(fused_potential_spectrum(pl, xyz, g, s));
+    if ((s & 1) == 0) RC(fused_potential_pair(pl, s));
     PassArgs a3 = pass_x(pl);
-    a3.in0 = pl->B; a3.out = pl->C;
-    HIPCHK(c, lds_pass(m1, XF_INV, MID_EXPIV, XF_FWD, true, a3, c->stream));
+    a3.in0 = pl->B; a3.out = pl->C; a3.scale = pl->p.imPot;
+    HIPCHK(c, lds_pass(m1, XF_INV, (s & 1) ? MID_EXPIV_IM : MID_EXPIV_RE, XF_FWD, true, a3, c->stream));
     PassArgs a4 = pass_y(pl);
     a4.in0 = pl->C; a4.out = pl->E; a4.scale = 1.f / ((float)pl->m12); a4.mindim = m1 < m2 ? m1 : m2;
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, c->stream));
@@ -324,7 +329,7 @@ int slice_loop(fdes_plan* pl, int nslices)
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
     if (pl->fused) {
         RC(fused_enter(pl));
-        for (int s = 0; s < nslices; s++) RC(fused_slice(pl, pl->xyzFP_d, g, s));
+        for (int s = 0; s < nslices; s++) RC(fused_slice(pl, s));
         return fused_leave(pl);
     }
     for (int s = 0; s < nslices; s++) {
@@ -460,7 +465,7 @@ int fdes_plan_destroy(fdes_plan* pl)
     pl->lanes.clear();
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {pl->Z_d, pl->spec_d, pl->xyz0_d, pl->xyzTO_d, pl->xyzK_d, pl->xyzFP_d, pl->dwf_d, pl->occ_d, pl->bins.keys,
-                    pl->bins.keys_sorted, pl->bins.vals, pl->bins.order, pl->bins.seg, pl->bins.tmp, pl->D, pl->VH, pl->T, pl->PSI,
+                    pl->bins.keys_sorted, pl->bins.vals, pl->bins.order, pl->bins.seg, pl->bins.tmp, pl->bins.recs, pl->bins.recs_sorted, pl->bins.rowstart, pl->D, pl->VH, pl->T, pl->PSI,
                     pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A, pl->B, pl->C, pl->E, pl->F, pl->PSIH, pl->PT, pl->GT};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (auto& e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -529,6 +534,8 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLCHK(dmalloc(c, &pl->bins.vals, (size_t)nAt));
     PLCHK(dmalloc(c, &pl->bins.order, (size_t)nAt));
     PLCHK(dmalloc(c, &pl->bins.seg, (size_t)pl->bins_cap_keys + 2));
+    PLCHK(dmalloc(c, &pl->bins.recs, (size_t)nAt));
+    PLCHK(dmalloc(c, &pl->bins.recs_sorted, (size_t)nAt));
     pl->bins.tmp_bytes = geom_sort_temp_bytes(nAt);
     PLHIP(hipMalloc(&pl->bins.tmp, pl->bins.tmp_bytes > 0 ? pl->bins.tmp_bytes : 16));
     {   // enough blocks for an average segment, capped; the kernel strides over the rest
@@ -583,6 +590,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         PLCHK(dmalloc(c, &pl->PSIH, pl->m12));
         PLCHK(dmalloc(c, &pl->PT, pl->m12));
         PLCHK(dmalloc(c, &pl->GT, pl->m12 * (size_t)pl->nZ));
+        PLCHK(dmalloc(c, &pl->bins.rowstart, (size_t)pl->p.m3 * pl->nZ * (size_t)(pl->p.m2 + 1)));
         PLHIP(k_build_propagator(pl->PT, pl->kp, 1, c->stream));
         for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 1, c->stream));
     }
@@ -818,10 +826,11 @@ int fdes_plan_tap_potential(fdes_plan* pl, int k, int j, int s, float* V)
     RC(config_atoms(pl, k, j < 0 ? 0 : j));
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
     if (pl->fused) {
-        RC(fused_potential_spectrum(pl, pl->xyzFP_d, g, s));
+        RC(fused_potential_pair(pl, s & ~1));
         PassArgs a = pass_x(pl);
-        a.in0 = pl->B; a.out = pl->VH;
+        a.in0 = pl->B; a.out = pl->T;
         HIPCHK(c, lds_pass(pl->p.m1, XF_INV, MID_NONE, XF_NONE, false, a, c->stream));
+        HIPCHK(c, k_pick_potential(pl->VH, pl->T, pl->m12, s & 1, pl->p.imPot, c->stream));
     } else {
         RC(phase_grating(pl, pl->xyzFP_d, g, s));
     }
@@ -970,7 +979,7 @@ int fdes_build_measurements(fdes_ctx* c, const fdes_params* p, const fdes_atoms*
         // ratio == 1, frPh == 0 and the last specimen tilt is zero).
         const float inv = 1.f / (float)pl->ratio;
         BinGeom g{pl->p.m1, pl->p.m2, (int)(((float)pl->p.m3) * inv), pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3 / inv};
-        hipError_t e = geom_bin_atoms(pl->xyzTO_d, pl->spec_d, pl->nAt, g, pl->bins, c->stream);
+        hipError_t e = geom_bin_atoms(pl->xyzTO_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, false, c->stream);
         if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = FDES_EGPU; }
         for (int s = 0; s < g.m3 && rc == FDES_OK; s++) {
             rc = phase_grating(pl, pl->xyzTO_d, g, s);

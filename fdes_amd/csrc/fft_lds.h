@@ -21,7 +21,10 @@ enum MidKind {
     MID_MULPSI = 5, // (row of in0) (x) (row of in1), both inverse transformed first (multiplyElementwise)
     MID_PTAB = 6,   // spectrum (x) P[row][col]                          (multiplyElementwise with frProp)
     MID_SCALE = 7,  // * scale
-    MID_GTABN = 8   // MID_GTAB with a species loop (nspecies > 1)
+    MID_GTABN = 8,  // MID_GTAB with a species loop (nspecies > 1)
+    MID_ATOMS = 9,  // source rows are built from the sorted atom records (re: slice q0, im: slice q1), no grid read
+    MID_EXPIV_RE = 10, // t = exp(-scale * v) (cos v, sin v) with v = Re(row)  (two slices packed per potential grid)
+    MID_EXPIV_IM = 11  // ... v = Im(row)
 };
 
 struct PassArgs {
@@ -39,6 +42,10 @@ struct PassArgs {
     float scale = 1.f;
     int mindim = 0;              // min(m1, m2) for the band limit
     int wg = 512;                // threads per workgroup (512 or 256)
+    // MID_ATOMS
+    const void* recs = nullptr;  // AtomRec[] sorted by (slice, species, row)
+    const int* rowstart = nullptr; // [q][nrows + 1]
+    int q0 = -1, q1 = -1;        // (slice * nZ + species) deposited into the real / imaginary component (-1: none)
 };
 
 // Row lengths the kernels are instantiated for.

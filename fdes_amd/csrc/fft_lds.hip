@@ -19,6 +19,7 @@
 // XCD (blockIdx % 8 equal) own consecutive row groups and their partial 128-byte lines merge in
 // that XCD's L2.
 #include "fft_lds.h"
+#include "geometry.h"
 
 #include <cmath>
 
@@ -327,10 +328,52 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
 #pragma unroll
             for (int l = 0; l < 16; l++) a[h][l] = acc[h][l];
     } else {
+        if constexpr (MID == MID_ATOMS) {
+            // squareAtoms_d (src/crystalMaker.cu:73-123) without a deposit grid: the few atoms whose bilinear
+            // footprint touches this row group are read from the (slice, species, row)-sorted records and added
+            // straight into the registers of the threads that own the four pixels.  Every thread walks the same
+            // atoms (uniform control flow); contributions are added in sorted order (deterministic).
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) a[h][l] = make_float2(0.f, 0.f);
+            const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs);
+#pragma unroll 1
+            for (int comp = 0; comp < 2; comp++) {
+                const int q = comp ? A.q1 : A.q0;
+                if (q < 0) continue;
+                const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
+                const int rlo = row0 > 0 ? row0 - 1 : 0;
+                const int rhi = (row0 + R + 1 < A.nrows) ? row0 + R + 1 : A.nrows;
+                const int plo = rs[rlo], phi = rs[rhi];
+#pragma unroll 1
+                for (int p = plo; p < phi; p++) {
+                    const AtomRec ar = recs[p];
+                    const float a1 = fabsf(ar.r1), a2 = fabsf(ar.r2);
+                    const int s1 = ar.r1 < 0.f ? -1 : 1, s2 = ar.r2 < 0.f ? -1 : 1;
+#pragma unroll
+                    for (int px = 0; px < 4; px++) {
+                        // pixel order of the reference: (i1,i2), (i1,i2+s2), (i1+s1,i2+s2), (i1+s1,i2)
+                        const int c = ar.i1 + ((px == 2 || px == 3) ? s1 : 0);
+                        const int rr = ar.i2 + ((px == 1 || px == 2) ? s2 : 0) - row0;
+                        float w = ((px == 2 || px == 3) ? a1 : (1 - a1)) * ((px == 1 || px == 2) ? a2 : (1 - a2)) * ar.occ;
+                        if (rr < 0 || rr >= R) continue;
+                        if ((rr % RH) != r || (c % T) != t) continue;
+                        const int hh = rr / RH, ll = c / T;
+#pragma unroll
+                        for (int h = 0; h < NR; h++)
+#pragma unroll
+                            for (int l = 0; l < 16; l++)
+                                if (h == hh && l == ll) { if (comp) a[h][l].y += w; else a[h][l].x += w; }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int h = 0; h < NR; h++)
 #pragma unroll
             for (int l = 0; l < 16; l++) a[h][l] = A.in0[rbase[h] + t + T * l];
+        }
         if constexpr (MID == MID_ZSRC) {
 #pragma unroll
             for (int h = 0; h < NR; h++)
@@ -346,6 +389,18 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
                     const float e = __expf(-a[h][l].y);
                     float sn, cs;
                     sincos_cw(a[h][l].x, sn, cs);
+                    a[h][l] = make_float2(e * cs, e * sn);
+                }
+        } else if constexpr (MID == MID_EXPIV_RE || MID == MID_EXPIV_IM) {
+            // two slices share one potential grid: V_s = Re, V_{s+1} = Im; absorption V.y = imPot * V.x
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) {
+                    const float v = (MID == MID_EXPIV_RE) ? a[h][l].x : a[h][l].y;
+                    const float e = __expf(-(v * A.scale));
+                    float sn, cs;
+                    sincos_cw(v, sn, cs);
                     a[h][l] = make_float2(e * cs, e * sn);
                 }
         } else if constexpr (MID == MID_MASK) {
@@ -449,6 +504,9 @@ template <int N, int WG> hipError_t dispatch(int pre, int mid, int post, bool st
     CASE(XF_FWD, MID_NONE, XF_NONE, true)    // generic 2-D FFT passes
     CASE(XF_INV, MID_NONE, XF_NONE, true)
     CASE(XF_FWD, MID_ZSRC, XF_NONE, true)    // P1: deposit grid -> x spectrum
+    CASE(XF_FWD, MID_ATOMS, XF_NONE, true)   // P1': atom records -> x spectrum of two slices (re / im)
+    CASE(XF_INV, MID_EXPIV_RE, XF_FWD, true) // P3 on the real / imaginary component of a packed potential
+    CASE(XF_INV, MID_EXPIV_IM, XF_FWD, true)
     CASE(XF_FWD, MID_GTAB, XF_INV, true)     // P2: y FFT * f_e/sinc, y IFFT (one species)
     CASE(XF_FWD, MID_GTABN, XF_INV, true)    // P2: y FFT * f_e/sinc, species sum, y IFFT
     CASE(XF_INV, MID_EXPIV, XF_FWD, true)    // P3: x IFFT, exp(iV), x FFT

@@ -11,9 +11,18 @@ struct BinGeom { // what squareAtoms_d reads from params_t (src/crystalMaker.cu:
     float d1, d2, d3;
 };
 
-struct AtomBins { // device buffers of the per-configuration (slice, species) binning
+// What one deposited atom needs (squareAtoms_d, src/crystalMaker.cu:85-99): nearest pixel, signed offsets, occupancy.
+struct AtomRec {
+    int i1, i2;
+    float r1, r2, occ;
+    int pad;
+};
+
+struct AtomBins { // device buffers of the per-configuration binning, key = (slice * nZ + species) * m2 + row
     uint32_t *keys = nullptr, *keys_sorted = nullptr, *vals = nullptr, *order = nullptr;
-    int* seg = nullptr; // [m3*nZ + 2]
+    int* seg = nullptr;      // [m3*nZ + 2]  first sorted position of every (slice, species)
+    int* rowstart = nullptr; // [m3*nZ][m2 + 1] first sorted position of every (slice, species, row); nullptr = not built
+    AtomRec *recs = nullptr, *recs_sorted = nullptr;
     void* tmp = nullptr;
     size_t tmp_bytes = 0;
 };
@@ -21,7 +30,8 @@ struct AtomBins { // device buffers of the per-configuration (slice, species) bi
 hipError_t geom_srot(float* xyz, int nAt, int ax, int ay, float c, float s, hipStream_t st);
 hipError_t geom_jitter(float* out, const float* in, const float* dwf, int nAt, uint32_t seed, int k, int j, hipStream_t st);
 size_t geom_sort_temp_bytes(int nAt);
-hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, int nAt, const BinGeom& g, AtomBins& b, hipStream_t st);
+hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, const float* occ, int nAt, const BinGeom& g, AtomBins& b, bool with_rows,
+                          hipStream_t st);
 hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key, const BinGeom& g,
                         float imPot, int blocks, hipStream_t st);
 

@@ -41,33 +41,58 @@ __global__ void k_jitter(float* __restrict__ out, const float* __restrict__ in, 
     }
 }
 
-// key = i3 * nZ + species for atoms that squareAtoms_d would deposit in some slice, else nkeys.
-__global__ void k_atom_keys(const float* __restrict__ xyz, const uint8_t* __restrict__ spec, int nAt, BinGeom g,
-                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+// key = ((i3 * nZ + species) * m2 + i2) for atoms that squareAtoms_d would deposit in some slice (i2 = nearest
+// row), else nq * m2 (sorted to the end).  Also records what the deposit needs.
+__global__ void k_atom_keys(const float* __restrict__ xyz, const uint8_t* __restrict__ spec, const float* __restrict__ occ, int nAt,
+                            BinGeom g, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, AtomRec* __restrict__ recs)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nAt; i += gridDim.x * blockDim.x) {
         const float x1 = xyz[i * 3 + 0] / g.d1 + ((float)g.m1) * 0.5f - 0.5f;
         const float x2 = xyz[i * 3 + 1] / g.d2 + ((float)g.m2) * 0.5f - 0.5f;
         const float z3 = roundf(xyz[i * 3 + 2] / g.d3 + ((float)g.m3) * 0.5f - 0.5f);
-        uint32_t key = (uint32_t)(g.m3 * g.nZ);
+        uint32_t key = (uint32_t)(g.m3 * g.nZ) * (uint32_t)g.m2;
         const bool inside = (x1 > 1.f) && (x1 < (float)(g.m1 - 2)) && (x2 > 1.f) && (x2 < (float)(g.m2 - 2));
-        if (inside && z3 >= 0.f && z3 < (float)g.m3) key = (uint32_t)((int)z3 * g.nZ + (int)spec[i]);
+        const int i1 = (int)roundf(x1), i2 = (int)roundf(x2);
+        if (inside && z3 >= 0.f && z3 < (float)g.m3) key = (uint32_t)((int)z3 * g.nZ + (int)spec[i]) * (uint32_t)g.m2 + (uint32_t)i2;
         keys[i] = key;
         vals[i] = (uint32_t)i;
+        AtomRec r;
+        r.i1 = i1; r.i2 = i2; r.r1 = x1 - (float)i1; r.r2 = x2 - (float)i2; r.occ = occ[i]; r.pad = 0;
+        recs[i] = r;
     }
 }
 
-// seg[q] = first sorted position whose key >= q, q = 0..nkeys (lower bound)
-__global__ void k_seg_bounds(const uint32_t* __restrict__ sorted, int nAt, int nkeys, int* __restrict__ seg)
+__global__ void k_gather_recs(AtomRec* __restrict__ out, const AtomRec* __restrict__ in, const uint32_t* __restrict__ order, int nAt)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > nkeys) return;
-    int lo = 0, hi = nAt;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < nAt; p += gridDim.x * blockDim.x) out[p] = in[order[p]];
+}
+
+__device__ inline int lower_bound_u32(const uint32_t* __restrict__ sorted, int n, uint32_t key)
+{
+    int lo = 0, hi = n;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (sorted[mid] < (uint32_t)q) lo = mid + 1; else hi = mid;
+        if (sorted[mid] < key) lo = mid + 1; else hi = mid;
     }
-    seg[q] = lo;
+    return lo;
+}
+
+// seg[q] = first sorted position of (slice, species) q = 0..nq (lower bound of q * m2)
+__global__ void k_seg_bounds(const uint32_t* __restrict__ sorted, int nAt, int nq, int m2, int* __restrict__ seg)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nq) return;
+    seg[q] = lower_bound_u32(sorted, nAt, (uint32_t)q * (uint32_t)m2);
+}
+
+// rowstart[q * (m2 + 1) + row] = first sorted position with key >= q * m2 + row, row = 0..m2
+__global__ void k_row_starts(const uint32_t* __restrict__ sorted, int nAt, int nq, int m2, int* __restrict__ rowstart)
+{
+    const size_t n = (size_t)nq * (size_t)(m2 + 1);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t q = (uint32_t)(e / (size_t)(m2 + 1)), row = (uint32_t)(e % (size_t)(m2 + 1));
+        rowstart[e] = lower_bound_u32(sorted, nAt, q * (uint32_t)m2 + row);
+    }
 }
 
 __device__ inline int signum(float x) { return x < 0.f ? -1 : 1; }
@@ -139,20 +164,35 @@ size_t geom_sort_temp_bytes(int nAt)
     return bytes;
 }
 
-hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, int nAt, const BinGeom& g, AtomBins& b, hipStream_t st)
+hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, const float* occ, int nAt, const BinGeom& g, AtomBins& b,
+                          bool with_rows, hipStream_t st)
 {
-    const int nkeys = g.m3 * g.nZ;
-    if (nAt <= 0) return hipMemsetAsync(b.seg, 0, sizeof(int) * (size_t)(nkeys + 2), st);
-    hipLaunchKernelGGL(k_atom_keys, dim3(blocks_for(nAt, 256, 2048)), dim3(256), 0, st, xyz, spec, nAt, g, b.keys, b.vals);
+    const int nq = g.m3 * g.nZ;
+    if (nAt <= 0) {
+        hipError_t e0 = hipMemsetAsync(b.seg, 0, sizeof(int) * (size_t)(nq + 2), st);
+        if (e0 == hipSuccess && with_rows && b.rowstart) e0 = hipMemsetAsync(b.rowstart, 0, sizeof(int) * (size_t)nq * (size_t)(g.m2 + 1), st);
+        return e0;
+    }
+    hipLaunchKernelGGL(k_atom_keys, dim3(blocks_for(nAt, 256, 2048)), dim3(256), 0, st, xyz, spec, occ, nAt, g, b.keys, b.vals, b.recs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    const uint64_t nkeys = (uint64_t)nq * (uint64_t)g.m2;
     unsigned bits = 1;
-    while ((1u << bits) <= (unsigned)nkeys && bits < 32) bits++;
+    while ((1ull << bits) <= nkeys && bits < 32) bits++;
     size_t tb = b.tmp_bytes;
     e = rocprim::radix_sort_pairs(b.tmp, tb, b.keys, b.keys_sorted, b.vals, b.order, (size_t)nAt, 0u, bits, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_seg_bounds, dim3((nkeys + 1 + 255) / 256), dim3(256), 0, st, b.keys_sorted, nAt, nkeys, b.seg);
-    return hipGetLastError();
+    hipLaunchKernelGGL(k_seg_bounds, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, b.keys_sorted, nAt, nq, g.m2, b.seg);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (with_rows && b.rowstart) {
+        hipLaunchKernelGGL(k_gather_recs, dim3(blocks_for(nAt, 256, 2048)), dim3(256), 0, st, b.recs_sorted, b.recs, b.order, nAt);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        const size_t n = (size_t)nq * (size_t)(g.m2 + 1);
+        hipLaunchKernelGGL(k_row_starts, dim3(blocks_for((int)(n > 0x7fffffff ? 0x7fffffff : n), 256, 4096)), dim3(256), 0, st, b.keys_sorted,
+                           nAt, nq, g.m2, b.rowstart);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key, const BinGeom& g,

@@ -26,6 +26,7 @@ hipError_t k_axpy(float2* y, const float2* x, size_t n, float alpha, hipStream_t
 // Vhat = (first ? 0 : Vhat) + Dhat * g_Z(q) ; Dhat = 0   (projectedPotential_d * divideBySinc * multiplyWith...)
 hipError_t k_filter_accum(float2* Vhat, float2* Dhat, const KP& p, const Kirk& kz, int first, hipStream_t st);
 hipError_t k_transmit(float2* t, const float2* V, size_t n, hipStream_t st);
+hipError_t k_pick_potential(float2* V, const float2* W, size_t n, int comp, float imPot, hipStream_t st);
 hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st);
 hipError_t k_mul(float2* dst, const float2* f0, const float2* f1, size_t n, hipStream_t st); // dst = f0 (x) f1, 3-mult
 hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_t st);

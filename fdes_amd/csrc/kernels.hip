@@ -149,6 +149,12 @@ __global__ void kk_mask_scale(float2* __restrict__ f, int m1, int m2, float alph
     }
 }
 
+// Packed potential W = V_s + i V_{s+1} -> V of one slice as the reference holds it: (v, imPot * v)
+__global__ void kk_pick_potential(float2* __restrict__ V, const float2* __restrict__ W, size_t n, int comp, float imPot)
+{
+    GS_LOOP(i, n) { const float2 w = W[i]; const float v = comp ? w.y : w.x; V[i] = make_float2(v, v * imPot); }
+}
+
 // ---- multiplyElementwise (src/complexMath.cu:44-62): 3-multiply product, f0 = (a, b), f1 = (c, d)
 __device__ __forceinline__ float2 cmul3(float2 f0, float2 f1)
 {
@@ -434,6 +440,7 @@ hipError_t k_filter_accum(float2* Vh, float2* Dh, const KP& p, const Kirk& kz, i
     LAUNCH(kk_filter_accum, (size_t)p.m1 * p.m2, st, Vh, Dh, p, kz, first);
 }
 hipError_t k_transmit(float2* t, const float2* V, size_t n, hipStream_t st) { LAUNCH(kk_transmit, n, st, t, V, n); }
+hipError_t k_pick_potential(float2* V, const float2* W, size_t n, int comp, float imPot, hipStream_t st) { LAUNCH(kk_pick_potential, n, st, V, W, n, comp, imPot); }
 hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st)
 {
     LAUNCH(kk_mask_scale, (size_t)m1 * m2, st, f, m1, m2, alpha);
