@@ -189,6 +189,7 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
     using G_ = Geo<N, WG>;
     constexpr int T = G_::T;
     constexpr int NW = (T + 63) / 64;
+    const int rd0 = t + (t >> 4); // read base: padi(t)
     // ---- stage 0
 #pragma unroll
     for (int h = 0; h < NR; h++) r16<INV>(a[h]);
@@ -203,14 +204,14 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
     for (int h = 0; h < NR; h++) {
         float2* row = lds + (r + h * G_::RH) * G_::LDROW;
 #pragma unroll
-        for (int k = 0; k < 16; k++) row[padi(16 * t + k)] = a[h][k];
+        for (int k = 0; k < 16; k++) row[17 * t + k] = a[h][k]; // padi(16 t + k)
     }
     group_sync<NW>(gs);
 #pragma unroll
     for (int h = 0; h < NR; h++) {
         const float2* row = lds + (r + h * G_::RH) * G_::LDROW;
 #pragma unroll
-        for (int l = 0; l < 16; l++) a[h][l] = row[padi(t + T * l)];
+        for (int l = 0; l < 16; l++) a[h][l] = row[rd0 + (T + T / 16) * l]; // padi(t + T l): T is a multiple of 16
     }
     // ---- stage 1
 #pragma unroll
@@ -228,14 +229,14 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
         for (int h = 0; h < NR; h++) {
             float2* row = lds + (r + h * G_::RH) * G_::LDROW;
 #pragma unroll
-            for (int k = 0; k < 16; k++) row[padi(q + 256 * p + 16 * k)] = a[h][k];
+            for (int k = 0; k < 16; k++) row[q + 272 * p + 17 * k] = a[h][k]; // padi(q + 256 p + 16 k), q < 16
         }
         group_sync<NW>(gs);
 #pragma unroll
         for (int h = 0; h < NR; h++) {
             const float2* row = lds + (r + h * G_::RH) * G_::LDROW;
 #pragma unroll
-            for (int l = 0; l < 16; l++) a[h][l] = row[padi(t + T * l)];
+            for (int l = 0; l < 16; l++) a[h][l] = row[rd0 + (T + T / 16) * l]; // padi(t + T l): T is a multiple of 16
         }
         // ---- stage 2: G butterflies of radix R3 over registers {i + G j}
 #pragma unroll
@@ -291,13 +292,21 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
     int bg = (int)blockIdx.x;
     if ((gridDim.x & 7) == 0) bg = (bg & 7) * ((int)gridDim.x >> 3) + (bg >> 3);
     const int row0 = bg * R;
-    size_t rbase[NR];
+    // uniform row-group base (scalar registers) + 32-bit per-thread element offsets (< R * N = 16384)
+    const size_t gbase = (size_t)row0 * N;
+    unsigned rbase[NR];
     int grow[NR];
 #pragma unroll
     for (int h = 0; h < NR; h++) {
         grow[h] = row0 + r + h * RH;
-        rbase[h] = (size_t)grow[h] * N;
+        rbase[h] = (unsigned)((r + h * RH) * N);
     }
+    const float2* __restrict__ in0 = A.in0 ? A.in0 + gbase : nullptr;
+    const float2* __restrict__ in1 = A.in1 ? A.in1 + gbase : nullptr;
+    const float2* __restrict__ ptab = A.ptab ? A.ptab + gbase : nullptr;
+    const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
+    float2* __restrict__ zsrc = A.zsrc ? A.zsrc + gbase : nullptr;
+    float2* __restrict__ outn = A.out + gbase;
 
     float2 a[NR][16];
     if constexpr (MID == MID_GTABN) {
@@ -312,13 +321,13 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
-                for (int l = 0; l < 16; l++) a[h][l] = A.in0[zo + rbase[h] + t + T * l];
+                for (int l = 0; l < 16; l++) a[h][l] = in0[zo + rbase[h] + t + T * l];
             xform<N, WG, PRE, true>(a, lds, r, t, tw0, tw1, gs);
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
-                    const float gv = A.gtab[zo + rbase[h] + t + T * l];
+                    const float gv = gtab[zo + rbase[h] + t + T * l];
                     acc[h][l].x += a[h][l].x * gv;
                     acc[h][l].y += a[h][l].y * gv;
                 }
@@ -338,47 +347,76 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = make_float2(0.f, 0.f);
             const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs);
-#pragma unroll 1
+            // candidate ranges of both components (4 independent loads), then the records are staged through LDS
+            // (free before the first exchange) so that the walk below is not a chain of dependent global loads
+            const int rlo = row0 > 0 ? row0 - 1 : 0;
+            const int rhi = (row0 + R + 1 < A.nrows) ? row0 + R + 1 : A.nrows;
+            int plo[2] = {0, 0}, phi[2] = {0, 0};
+#pragma unroll
             for (int comp = 0; comp < 2; comp++) {
                 const int q = comp ? A.q1 : A.q0;
-                if (q < 0) continue;
-                const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
-                const int rlo = row0 > 0 ? row0 - 1 : 0;
-                const int rhi = (row0 + R + 1 < A.nrows) ? row0 + R + 1 : A.nrows;
-                const int plo = rs[rlo], phi = rs[rhi];
+                if (q >= 0) {
+                    const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
+                    plo[comp] = rs[rlo];
+                    phi[comp] = rs[rhi];
+                }
+            }
+            if (phi[0] - plo[0] + phi[1] - plo[1] == 0) {
+                // empty row group: its spectrum is zero
+                if constexpr (STORE_T) {
+#pragma unroll
+                    for (int it = 0; it < NR * 16; it++) {
+                        const int e = it * WG + tid;
+                        (A.out + row0)[(unsigned)(e / R) * (unsigned)A.nrows + (unsigned)(e & (R - 1))] = make_float2(0.f, 0.f);
+                    }
+                }
+                return;
+            }
+            AtomRec* sh = reinterpret_cast<AtomRec*>(lds);
+            constexpr int CAP = 2048;
 #pragma unroll 1
-                for (int p = plo; p < phi; p++) {
-                    const AtomRec ar = recs[p];
-                    const float a1 = fabsf(ar.r1), a2 = fabsf(ar.r2);
-                    const int s1 = ar.r1 < 0.f ? -1 : 1, s2 = ar.r2 < 0.f ? -1 : 1;
+            for (int comp = 0; comp < 2; comp++) {
+#pragma unroll 1
+                for (int base = plo[comp]; base < phi[comp]; base += CAP) {
+                    const int nb = (phi[comp] - base < CAP) ? phi[comp] - base : CAP;
+                    __syncthreads();
+                    for (int i = tid; i < nb; i += WG) sh[i] = recs[base + i];
+                    __syncthreads();
+#pragma unroll 1
+                    for (int p = 0; p < nb; p++) {
+                        const AtomRec ar = sh[p];
+                        const float a1 = fabsf(ar.r1), a2 = fabsf(ar.r2);
+                        const int s1 = ar.r1 < 0.f ? -1 : 1, s2 = ar.r2 < 0.f ? -1 : 1;
 #pragma unroll
-                    for (int px = 0; px < 4; px++) {
-                        // pixel order of the reference: (i1,i2), (i1,i2+s2), (i1+s1,i2+s2), (i1+s1,i2)
-                        const int c = ar.i1 + ((px == 2 || px == 3) ? s1 : 0);
-                        const int rr = ar.i2 + ((px == 1 || px == 2) ? s2 : 0) - row0;
-                        float w = ((px == 2 || px == 3) ? a1 : (1 - a1)) * ((px == 1 || px == 2) ? a2 : (1 - a2)) * ar.occ;
-                        if (rr < 0 || rr >= R) continue;
-                        if ((rr % RH) != r || (c % T) != t) continue;
-                        const int hh = rr / RH, ll = c / T;
+                        for (int px = 0; px < 4; px++) {
+                            // pixel order of the reference: (i1,i2), (i1,i2+s2), (i1+s1,i2+s2), (i1+s1,i2)
+                            const int c = ar.i1 + ((px == 2 || px == 3) ? s1 : 0);
+                            const int rr = ar.i2 + ((px == 1 || px == 2) ? s2 : 0) - row0;
+                            const float w = ((px == 2 || px == 3) ? a1 : (1 - a1)) * ((px == 1 || px == 2) ? a2 : (1 - a2)) * ar.occ;
+                            if (rr < 0 || rr >= R) continue;
+                            if ((rr % RH) != r || (c % T) != t) continue;
+                            const int hh = rr / RH, ll = c / T;
 #pragma unroll
-                        for (int h = 0; h < NR; h++)
+                            for (int h = 0; h < NR; h++)
 #pragma unroll
-                            for (int l = 0; l < 16; l++)
-                                if (h == hh && l == ll) { if (comp) a[h][l].y += w; else a[h][l].x += w; }
+                                for (int l = 0; l < 16; l++)
+                                    if (h == hh && l == ll) { if (comp) a[h][l].y += w; else a[h][l].x += w; }
+                        }
                     }
                 }
             }
+            __syncthreads(); // the staging area becomes the exchange buffer
         } else {
 #pragma unroll
         for (int h = 0; h < NR; h++)
 #pragma unroll
-            for (int l = 0; l < 16; l++) a[h][l] = A.in0[rbase[h] + t + T * l];
+            for (int l = 0; l < 16; l++) a[h][l] = in0[rbase[h] + t + T * l];
         }
         if constexpr (MID == MID_ZSRC) {
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
-                for (int l = 0; l < 16; l++) A.zsrc[rbase[h] + t + T * l] = make_float2(0.f, 0.f);
+                for (int l = 0; l < 16; l++) zsrc[rbase[h] + t + T * l] = make_float2(0.f, 0.f);
         }
         xform<N, WG, PRE, false>(a, lds, r, t, tw0, tw1, gs);
         if constexpr (MID == MID_EXPIV) {
@@ -404,14 +442,17 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
                     a[h][l] = make_float2(e * cs, e * sn);
                 }
         } else if constexpr (MID == MID_MASK) {
-            const float md = (float)A.mindim;
+            // zeroHighFreq tests (float)(i1^2 + i2^2) * 9 / mindim^2 > 1 (src/multisliceSimulation.cu:241).  On the
+            // power-of-two grids this kernel serves, mindim^2 < 2^24, so every float on the deciding side of the
+            // threshold is exact and the integer comparison is the same predicate, without 32 divisions per thread.
+            const int md2 = A.mindim * A.mindim;
 #pragma unroll
             for (int h = 0; h < NR; h++) {
                 const int i2 = iwc(grow[h], A.nrows);
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
                     const int i1 = iwc(t + T * l, N);
-                    const bool outside = ((float)(i1 * i1 + i2 * i2) * 9.f / (md * md)) > 1.f;
+                    const bool outside = 9 * (i1 * i1 + i2 * i2) > md2;
                     a[h][l] = outside ? make_float2(0.f, 0.f) : make_float2(a[h][l].x * A.scale, a[h][l].y * A.scale);
                 }
             }
@@ -425,20 +466,20 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
             for (int h = 0; h < NR; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
-                    const float gv = A.gtab[rbase[h] + t + T * l];
+                    const float gv = gtab[rbase[h] + t + T * l];
                     a[h][l] = make_float2(a[h][l].x * gv, a[h][l].y * gv);
                 }
         } else if constexpr (MID == MID_PTAB) {
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
-                for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], A.ptab[rbase[h] + t + T * l]);
+                for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], ptab[rbase[h] + t + T * l]);
         } else if constexpr (MID == MID_MULPSI) {
             float2 b[NR][16];
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
-                for (int l = 0; l < 16; l++) b[h][l] = A.in1[rbase[h] + t + T * l];
+                for (int l = 0; l < 16; l++) b[h][l] = in1[rbase[h] + t + T * l];
             xform<N, WG, PRE, true>(b, lds, r, t, tw0, tw1, gs);
 #pragma unroll
             for (int h = 0; h < NR; h++)
@@ -452,7 +493,7 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
 #pragma unroll
         for (int h = 0; h < NR; h++)
 #pragma unroll
-            for (int l = 0; l < 16; l++) A.out[rbase[h] + t + T * l] = a[h][l];
+            for (int l = 0; l < 16; l++) outn[rbase[h] + t + T * l] = a[h][l];
     } else {
         // stage the R x N tile as [c][r] (swizzled) and write R contiguous elements per output row
         __syncthreads();
@@ -466,13 +507,13 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
             }
         }
         __syncthreads();
-        float2* __restrict__ dst = A.out;
-        const int ld = A.nrows; // transposed grid: N rows of length nrows
+        float2* __restrict__ dst = A.out + row0; // transposed grid: N rows of length nrows
+        const unsigned ld = (unsigned)A.nrows;
+        const int rr = tid & (R - 1), c0 = tid / R; // WG is a multiple of R: rr is the same in every iteration
 #pragma unroll
         for (int it = 0; it < NR * 16; it++) {
-            const int e = it * WG + tid;
-            const int rr = e & (R - 1), c = e / R;
-            dst[(size_t)c * ld + row0 + rr] = lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))];
+            const int c = c0 + it * (WG / R);
+            dst[(unsigned)c * ld + (unsigned)rr] = lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))];
         }
     }
 }
