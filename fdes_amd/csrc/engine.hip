@@ -35,6 +35,7 @@ struct fdes_ctx {
     int opt_graph = 0;
     uint32_t seed = 1; // src/crystalMaker.cu:292
     bool is_lane_ctx = false;
+    int skip_empty = 1;   // slices without atoms: t = 1, only the Fresnel step is applied (fused loop)
     int lanes = 2;        // configurations in flight at once (own stream + buffers each) in the fused slice loop
     int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
@@ -76,6 +77,8 @@ struct fdes_plan {
     bool is_lane = false;
     unsigned rr = 0;                    // round-robin lane selector
     bool lanes_dirty = false;           // lanes hold partial sums not yet folded into lane 0
+    std::vector<int> seg_h;             // host copy of the (slice, species) segment table of the current configuration
+    int64_t slices_skipped = 0;
     float2 *A = nullptr, *B = nullptr, *C = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
     float* GT = nullptr;
     std::vector<EvPair> probe;
@@ -178,6 +181,14 @@ int config_atoms(fdes_plan* pl, int k, int j)
         HIPCHK(c, hipMemcpyAsync(pl->xyzFP_d, pl->xyzK_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, c->stream));
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
     HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, pl->fused, c->stream));
+    if (pl->fused && c->skip_empty) {
+        // which slices hold atoms decides the launch sequence: one small D2H per configuration
+        pl->seg_h.resize((size_t)pl->p.m3 * pl->nZ + 1);
+        HIPCHK(c, hipMemcpyAsync(pl->seg_h.data(), pl->bins.seg, sizeof(int) * pl->seg_h.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        pl->seg_h.clear();
+    }
     return FDES_OK;
 }
 
@@ -255,7 +266,23 @@ int fused_slice(fdes_plan* pl, int s)
 {
     fdes_ctx* c = pl->ctx;
     const int m1 = pl->p.m1, m2 = pl->p.m2;
-    if ((s & 1) == 0) RC(fused_potential_pair(pl, s));
+    auto empty = [&](int q) { return q >= pl->p.m3 || pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ]; };
+    const bool have_seg = !pl->seg_h.empty();
+    if (have_seg && empty(s)) {
+        // no atom in this slice: V = 0, t = BL(1) = 1; psi <- F^-1[P F[psi]].  PSIH is [y][kx]: a transposing
+        // copy gives the y-pass its rows, then the usual propagator pass.
+        PassArgs a5 = pass_x(pl);
+        a5.in0 = pl->PSIH; a5.out = pl->F;
+        a5.scale = (float)m1; // P5 hands m1 * FFT_x(t psi) to P6 (unnormalised x round trip); exact power of two
+        HIPCHK(c, lds_pass(m1, XF_NONE, MID_SCALE, XF_NONE, true, a5, c->stream));
+        PassArgs a6 = pass_y(pl);
+        a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->PSIH;
+        HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
+        pl->slices_skipped++;
+        return FDES_OK;
+    }
+    // the pair's potential is needed by its first non-empty slice
+    if ((s & 1) == 0 || (have_seg && empty(s - 1))) RC(fused_potential_pair(pl, s & ~1));
     PassArgs a3 = pass_x(pl);
     a3.in0 = pl->B; a3.out = pl->C; a3.scale = pl->p.imPot;
     HIPCHK(c, lds_pass(m1, XF_INV, (s & 1) ? MID_EXPIV_IM : MID_EXPIV_RE, XF_FWD, true, a3, c->stream));
@@ -449,6 +476,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
     if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 256 && value != 512) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "skip_empty")) { c->skip_empty = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "lanes")) { if (value < 1 || value > 4) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "probe_stride")) { c->probe_stride = (int)value; return FDES_OK; }
     return FDES_EINVAL;
@@ -603,7 +631,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             fdes_ctx* lc = nullptr;
             PLCHK(fdes_create(&lc, c->device));
             lc->is_lane_ctx = true;
-            lc->opt_fft = c->opt_fft; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes;
+            lc->opt_fft = c->opt_fft; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty;
             pl->lane_ctx.push_back(lc);
             fdes_plan* lp = nullptr;
             int lrc = fdes_plan_create(lc, p_in, a, &lp);

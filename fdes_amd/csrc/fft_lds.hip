@@ -539,6 +539,7 @@ template <int N, int WG> hipError_t dispatch(int pre, int mid, int post, bool st
 #define CASE(P, M, Q, S) if (pre == P && mid == M && post == Q && st_t == S) return launch<N, WG, P, M, Q, S>(a, st);
     CASE(XF_NONE, MID_NONE, XF_NONE, false)  // copy (memory floor of the access pattern; micro-benchmark)
     CASE(XF_NONE, MID_NONE, XF_NONE, true)   // transpose-copy
+    CASE(XF_NONE, MID_SCALE, XF_NONE, true)  // scaled transpose-copy (empty-slice fast path)
     CASE(XF_FWD, MID_NONE, XF_NONE, false)   // real -> mixed, natural store            (start of a configuration)
     CASE(XF_INV, MID_NONE, XF_NONE, false)   // mixed -> real, natural store            (end of a configuration)
     CASE(XF_INV, MID_SCALE, XF_NONE, false)

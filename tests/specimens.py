@@ -48,7 +48,7 @@ def make_params(n3=1, **kw):
 
 
 def case_tiny(m=64, m3=4, nz=2, frPh=0, mode=0, n3=1, seed=3, tilt=False, beam_tilt=False, pD=0.0,
-              imPot=0.05, rect=False, nat=40, sub=1):
+              imPot=0.05, rect=False, nat=40, sub=1, zfrac=0.5):
     """Small random multi-species specimen on an m x m (rect: m x m/2) grid for fast parity tests."""
     rng = np.random.default_rng(seed)
     m1 = m
@@ -57,7 +57,7 @@ def case_tiny(m=64, m3=4, nz=2, frPh=0, mode=0, n3=1, seed=3, tilt=False, beam_t
     d = 0.2e-10
     Zs = np.array([79, 14, 8, 38][:nz], np.int32)
     Z = Zs[rng.integers(0, nz, nat)]
-    ext = np.array([m1 * d * 0.35, m2 * d * 0.35, m3 * 1.0e-10 * 0.5])
+    ext = np.array([m1 * d * 0.35, m2 * d * 0.35, m3 * 1.0e-10 * zfrac])  # zfrac < 0.5 leaves empty slices at both ends
     xyz = (rng.uniform(-1, 1, (nat, 3)) * ext).astype(np.float32)
     hp = make_params(n3, E0=80e3, n1=m1 - 2 * dn1, n2=m2 - 2 * dn2, dn1=dn1, dn2=dn2, d1=d, d2=d, m3=m3,
                      d3=1.0e-10, subSlTh=1.0e-10 / sub, frPh=frPh, mode=mode, pD=pD, imPot=imPot, C1_0=-2e-9,

@@ -73,3 +73,19 @@ def test_c1_reference_sized_case(engine, oracle):
     img = engine.build_measurements(hp, at)["image"]
     ref = oracle.build_measurements(hp, at, prec="f64")["image"]
     check(img, ref, oracle.build_measurements(hp, at, prec="f32")["image"], 1e-5, "C1 image")
+
+
+def test_empty_slice_fast_path(oracle):
+    """Slices without atoms: with skip_empty the engine only applies the Fresnel step (t = 1 exactly); both settings
+    must agree with the oracle, which always runs the full sequence."""
+    hp, at = S.case_tiny(m=256, m3=10, nz=2, nat=60, zfrac=0.18, frPh=2)
+    fdes_amd.consistent(hp)
+    ref = oracle.build_measurements(hp, at, prec="f64", want_exitwave=True)
+    outs = {}
+    for skip in (0, 1):
+        eng = fdes_amd.Engine(0, skip_empty=skip)
+        outs[skip] = eng.build_measurements(hp, at, want_exitwave=True)
+        eng.close()
+        check(outs[skip]["exitwave"], ref["exitwave"], None, 1e-5, f"exit wave, skip_empty={skip}")
+        check(outs[skip]["image"], ref["image"], None, 1e-5, f"image, skip_empty={skip}")
+    print("[parity] skip vs no-skip:", relerr(outs[1]["exitwave"], outs[0]["exitwave"].astype(np.float64)))
