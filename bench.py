@@ -124,8 +124,9 @@ def main():
             kname, alg_bytes = f"rocFFT 2-D C2C {m}x{m} (row + column kernels)", 32.0 * px
         ach = alg_bytes / per_launch_s / 1e9
         lanes = plan.lanes()
+        traffic = pmc_traffic(m) if fused else None
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
                 "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": int(fft_n),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 # `lanes` configurations run on their own streams: kernels of different lanes share the chip, so a
@@ -155,8 +156,9 @@ def main():
                        "wave": [m, m], "slices": m3, "atoms": atoms.n, "configs_per_step": world,
                        "parallelism": f"configs sharded over {world} GPU(s)"},
             "lanes": plan.lanes(), "skip_empty": args.skip_empty,
-            "device_slice_loop_ms_per_slice": round(loop_ms / max(loop_slices, 1), 5),
-            "full_step_algorithmic_GBps": round((176 + 56 * 1) * px * (loop_slices / max(loop_ms, 1e-9) * 1e3) / 1e9, 1),
+            # SURVEY 8d "full FDES step" figure (176 + 56 nZ) B/px per slice at the measured whole-GPU rate
+            "full_step_algorithmic_GBps": round((176 + 56 * 1) * px * (value / world) / 1e9, 1),
+            "lane_slice_loop_ms_per_slice": round(loop_ms / max(loop_slices, 1), 5),
             "slice_loop": "fused LDS passes" if fused else "rocFFT + point-wise kernels",
             "roofline": roof, "cpu_baseline": cpu, "finite": finite,
             "with_empty_slice_shortcut": extra,
@@ -166,6 +168,20 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(m):
+    """HBM bytes per launch of the probed kernel (P6) from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+    gfx950 correction + WRITE_SIZE; profiles/r01_pmc_traffic.json).  PMC counters cannot be collected from inside this
+    process, so the number is the offline measurement of the same kernel; None for sizes that were not profiled."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        for k, v in d.items():
+            if k.startswith(f"k_pass<{m},") and k.endswith("1, 6, 2, true>"):
+                return v["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(hp, atoms, m):

@@ -31,15 +31,22 @@ constexpr float C1 = 0.923879532511286756f; // cos(pi/8)
 constexpr float S1 = 0.382683432365089772f; // sin(pi/8)
 constexpr float C2 = 0.707106781186547524f; // cos(pi/4)
 
-__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// Complex values are native 2-vectors (clang ext_vector_type), not HIP's float2 struct: the backend then sees
+// <2 x float> adds / fmas and emits v_pk_add_f32 / v_pk_fma_f32 with op_sel / neg modifiers, instead of re-discovering
+// pairs by SLP (which packed unrelated scalars and cost a v_mov per four arithmetic instructions).
+typedef float cf __attribute__((ext_vector_type(2)));
+#define float2 cf
+#define make_float2(x, y) (cf{(x), (y)})
+__device__ __forceinline__ cf cmul(cf a, cf b) { return __builtin_elementwise_fma(a.yx, cf{-b.y, b.y}, a * b.xx); }
 // a * conj(b)
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+__device__ __forceinline__ cf cmulc(cf a, cf b) { return __builtin_elementwise_fma(a.yx, cf{b.y, -b.y}, a * b.xx); }
 // multiply by the forward twiddle w (INV = false) or its conjugate (INV = true)
 template <bool INV> __device__ __forceinline__ float2 twmul(float2 a, float2 w) { return INV ? cmulc(a, w) : cmul(a, w); }
 // multiply by -i (forward) / +i (inverse)
-template <bool INV> __device__ __forceinline__ float2 mul_mi(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+template <bool INV> __device__ __forceinline__ float2 mul_mi(float2 a) { return a.yx * (INV ? cf{-1.f, 1.f} : cf{1.f, -1.f}); }
+// b + (-i) a (forward) / b + i a (inverse), and b - (...): one packed fma each, the swap rides on op_sel
+template <bool INV> __device__ __forceinline__ float2 add_mi(float2 b, float2 a) { return __builtin_elementwise_fma(a.yx, (INV ? cf{-1.f, 1.f} : cf{1.f, -1.f}), b); }
+template <bool INV> __device__ __forceinline__ float2 sub_mi(float2 b, float2 a) { return __builtin_elementwise_fma(a.yx, (INV ? cf{1.f, -1.f} : cf{-1.f, 1.f}), b); }
 // 3-multiply complex product of the reference (src/complexMath.cu:44-62): f0 = (a, b), f1 = (c, d)
 __device__ __forceinline__ float2 cmul3(float2 f0, float2 f1)
 {
@@ -60,11 +67,11 @@ template <bool INV> __device__ __forceinline__ void r2(float2& x0, float2& x1)
 
 template <bool INV> __device__ __forceinline__ void r4(float2& x0, float2& x1, float2& x2, float2& x3)
 {
-    const float2 t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = mul_mi<INV>(x1 - x3);
+    const float2 t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, d = x1 - x3;
     x0 = t0 + t2;
-    x1 = t1 + t3;
+    x1 = add_mi<INV>(t1, d);
     x2 = t0 - t2;
-    x3 = t1 - t3;
+    x3 = sub_mi<INV>(t1, d);
 }
 
 // in-place 8-point DFT, natural order in and out
@@ -76,10 +83,10 @@ template <bool INV> __device__ __forceinline__ void r8(float2& a0, float2& a1, f
     r4<INV>(a1, a3, a5, a7); // c[1][k0] in a1,a3,a5,a7
     // twiddle c[1][k0] *= w8^k0
     a3 = twmul<INV>(a3, make_float2(C2, -C2));
-    a5 = mul_mi<INV>(a5);
     a7 = twmul<INV>(a7, make_float2(-C2, -C2));
-    // b[k0 + 4 k1] = c[0][k0] +- c[1][k0]
-    float2 b0 = a0 + a1, b4 = a0 - a1, b1 = a2 + a3, b5 = a2 - a3, b2 = a4 + a5, b6 = a4 - a5, b3 = a6 + a7, b7 = a6 - a7;
+    // b[k0 + 4 k1] = c[0][k0] +- c[1][k0]   (k0 = 2: the twiddle is -+i)
+    float2 b0 = a0 + a1, b4 = a0 - a1, b1 = a2 + a3, b5 = a2 - a3, b2 = add_mi<INV>(a4, a5), b6 = sub_mi<INV>(a4, a5), b3 = a6 + a7,
+           b7 = a6 - a7;
     a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
 }
 
@@ -272,8 +279,8 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
     using G_ = Geo<N, WG>;
     constexpr int T = G_::T, R = G_::R, RH = G_::RH;
     extern __shared__ float2 lds[];
-    const float2* __restrict__ tw0 = A.tw0;
-    const float2* __restrict__ tw1 = A.tw1;
+    const float2* __restrict__ tw0 = reinterpret_cast<const float2*>(A.tw0);
+    const float2* __restrict__ tw1 = reinterpret_cast<const float2*>(A.tw1);
     // per-group barrier words live behind the row buffers
     constexpr int NWG = (T + 63) / 64;
     unsigned* cnts = reinterpret_cast<unsigned*>(lds + (size_t)G_::LDROW * R);
@@ -301,12 +308,12 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
         grow[h] = row0 + r + h * RH;
         rbase[h] = (unsigned)((r + h * RH) * N);
     }
-    const float2* __restrict__ in0 = A.in0 ? A.in0 + gbase : nullptr;
-    const float2* __restrict__ in1 = A.in1 ? A.in1 + gbase : nullptr;
-    const float2* __restrict__ ptab = A.ptab ? A.ptab + gbase : nullptr;
+    const float2* __restrict__ in0 = A.in0 ? reinterpret_cast<const float2*>(A.in0) + gbase : nullptr;
+    const float2* __restrict__ in1 = A.in1 ? reinterpret_cast<const float2*>(A.in1) + gbase : nullptr;
+    const float2* __restrict__ ptab = A.ptab ? reinterpret_cast<const float2*>(A.ptab) + gbase : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
-    float2* __restrict__ zsrc = A.zsrc ? A.zsrc + gbase : nullptr;
-    float2* __restrict__ outn = A.out + gbase;
+    float2* __restrict__ zsrc = A.zsrc ? reinterpret_cast<float2*>(A.zsrc) + gbase : nullptr;
+    float2* __restrict__ outn = reinterpret_cast<float2*>(A.out) + gbase;
 
     float2 a[NR][16];
     if constexpr (MID == MID_GTABN) {
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
 #pragma unroll
                     for (int it = 0; it < NR * 16; it++) {
                         const int e = it * WG + tid;
-                        (A.out + row0)[(unsigned)(e / R) * (unsigned)A.nrows + (unsigned)(e & (R - 1))] = make_float2(0.f, 0.f);
+                        (reinterpret_cast<float2*>(A.out) + row0)[(unsigned)(e / R) * (unsigned)A.nrows + (unsigned)(e & (R - 1))] = make_float2(0.f, 0.f);
                     }
                 }
                 return;
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
             }
         }
         __syncthreads();
-        float2* __restrict__ dst = A.out + row0; // transposed grid: N rows of length nrows
+        float2* __restrict__ dst = reinterpret_cast<float2*>(A.out) + row0; // transposed grid: N rows of length nrows
         const unsigned ld = (unsigned)A.nrows;
         const int rr = tid & (R - 1), c0 = tid / R; // WG is a multiple of R: rr is the same in every iteration
 #pragma unroll
@@ -517,6 +524,9 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
         }
     }
 }
+
+#undef float2
+#undef make_float2
 
 template <int N, int WG, int PRE, int MID, int POST, bool ST> hipError_t launch(const PassArgs& a, hipStream_t st)
 {
