@@ -26,8 +26,8 @@ if ROOT not in sys.path:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=2048, help="wave size m (m x m), default the headline 2048")
     ap.add_argument("--slices", type=int, default=256)
     ap.add_argument("--cpu-baseline", type=int, default=1)

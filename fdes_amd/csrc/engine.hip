@@ -607,9 +607,10 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         const int m1 = pl->p.m1, m2 = pl->p.m2;
         const bool ok256 = (m2 % lds_fft_rows_per_block(m1, 256) == 0) && (m1 % lds_fft_rows_per_block(m2, 256) == 0) &&
                            lds_fft_rows_per_block(m1, 256) >= 4 && lds_fft_rows_per_block(m2, 256) >= 4; // >= 32-byte transposed segments
-        if (c->pass_threads == 256 && ok256) pl->wg = 256;
-        else if (c->pass_threads == 0 && c->lanes > 1 && ok256) pl->wg = 256;
-        else pl->wg = 512;
+        // 256-thread workgroups (two per CU) measured faster or equal for every pass up to 2048-point rows, with one
+        // or two lanes; 4096-point rows keep 512 threads (256 would cut the transposed-store segments to 16 bytes)
+        if (c->pass_threads == 512) pl->wg = 512;
+        else pl->wg = ok256 ? 256 : 512;
         PLCHK(dmalloc(c, &pl->A, pl->m12 * (size_t)pl->nZ));
         PLCHK(dmalloc(c, &pl->B, pl->m12));
         PLCHK(dmalloc(c, &pl->C, pl->m12));

@@ -189,9 +189,16 @@ template <int NW> __device__ __forceinline__ void group_sync(GroupSync& g)
 }
 
 // NR row FFTs at once, data in a[h][16] (a[h][l] = x_h[t + T l] on entry, X_h[t + T l] on exit).
-template <int N, int WG, bool INV, bool WAR0>
-__device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict__ lds, const int r, const int t,
-                                        const float2* __restrict__ tw0, const float2* __restrict__ tw1, GroupSync& gs)
+// Stage twiddles either sit in registers for the whole pass (TWR, 60 VGPRs: pays where the kernel stays under 256)
+// or are fetched from the L1/L2-resident tables at the point of use.
+struct Tw {
+    const float2* g0;
+    const float2* g1;
+    float2 r0[16], r1[16];
+};
+template <int N, int WG, bool INV, bool WAR0, bool TWR>
+__device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict__ lds, const int r, const int t, const Tw& tw,
+                                        GroupSync& gs)
 {
     using G_ = Geo<N, WG>;
     constexpr int T = G_::T;
@@ -202,7 +209,7 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
     for (int h = 0; h < NR; h++) r16<INV>(a[h]);
 #pragma unroll
     for (int k = 1; k < 16; k++) {
-        const float2 w = tw0[k * T + t];
+        const float2 w = TWR ? tw.r0[k] : tw.g0[k * T + t];
 #pragma unroll
         for (int h = 0; h < NR; h++) a[h][k] = twmul<INV>(a[h][k], w);
     }
@@ -227,7 +234,7 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
         const int q = t & 15, p = t >> 4;
 #pragma unroll
         for (int k = 1; k < 16; k++) {
-            const float2 w = tw1[k * (T / 16) + p];
+            const float2 w = TWR ? tw.r1[k] : tw.g1[k * (T / 16) + p];
 #pragma unroll
             for (int h = 0; h < NR; h++) a[h][k] = twmul<INV>(a[h][k], w);
         }
@@ -265,22 +272,23 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
     }
 }
 
-template <int N, int WG, int XF, bool WAR0>
-__device__ __forceinline__ void xform(float2 (&a)[NR][16], float2* lds, int r, int t, const float2* tw0, const float2* tw1,
-                                      GroupSync& gs)
+template <int N, int WG, int XF, bool WAR0, bool TWR>
+__device__ __forceinline__ void xform(float2 (&a)[NR][16], float2* lds, int r, int t, const Tw& tw, GroupSync& gs)
 {
-    if constexpr (XF == XF_FWD) row_fft<N, WG, false, WAR0>(a, lds, r, t, tw0, tw1, gs);
-    if constexpr (XF == XF_INV) row_fft<N, WG, true, WAR0>(a, lds, r, t, tw0, tw1, gs);
+    if constexpr (XF == XF_FWD) row_fft<N, WG, false, WAR0, TWR>(a, lds, r, t, tw, gs);
+    if constexpr (XF == XF_INV) row_fft<N, WG, true, WAR0, TWR>(a, lds, r, t, tw, gs);
 }
 
 template <int N, int WG, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(WG) void k_pass(PassArgs A)
+__global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
 {
     using G_ = Geo<N, WG>;
     constexpr int T = G_::T, R = G_::R, RH = G_::RH;
     extern __shared__ float2 lds[];
-    const float2* __restrict__ tw0 = reinterpret_cast<const float2*>(A.tw0);
-    const float2* __restrict__ tw1 = reinterpret_cast<const float2*>(A.tw1);
+    constexpr bool TWR = (MID != MID_MULPSI && MID != MID_PTAB && MID != MID_GTABN);
+    Tw tw;
+    tw.g0 = reinterpret_cast<const float2*>(A.tw0);
+    tw.g1 = reinterpret_cast<const float2*>(A.tw1);
     // per-group barrier words live behind the row buffers
     constexpr int NWG = (T + 63) / 64;
     unsigned* cnts = reinterpret_cast<unsigned*>(lds + (size_t)G_::LDROW * R);
@@ -295,6 +303,16 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
     // LDS slot per CU to another stream's kernel was slower than plain one-group workgroups on two streams.)
     const int tid = threadIdx.x;
     const int r = tid / T, t = tid % T;
+    // this thread's stage twiddles, loaded once (they serve every transform of the pass and both rows); issued first so
+    // their latency hides behind the row loads
+    if constexpr (TWR && (PRE != XF_NONE || POST != XF_NONE)) {
+#pragma unroll
+        for (int k = 1; k < 16; k++) tw.r0[k] = tw.g0[k * T + t];
+        if constexpr (G_::R3 > 1) {
+#pragma unroll
+            for (int k = 1; k < 16; k++) tw.r1[k] = tw.g1[k * (T / 16) + (t >> 4)];
+        }
+    }
     // XCD-aware remap: blocks with equal blockIdx % 8 share an XCD; give them consecutive row groups
     int bg = (int)blockIdx.x;
     if ((gridDim.x & 7) == 0) bg = (bg & 7) * ((int)gridDim.x >> 3) + (bg >> 3);
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
             for (int h = 0; h < NR; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = in0[zo + rbase[h] + t + T * l];
-            xform<N, WG, PRE, true>(a, lds, r, t, tw0, tw1, gs);
+            xform<N, WG, PRE, true, TWR>(a, lds, r, t, tw, gs);
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
 #pragma unroll
                 for (int l = 0; l < 16; l++) zsrc[rbase[h] + t + T * l] = make_float2(0.f, 0.f);
         }
-        xform<N, WG, PRE, false>(a, lds, r, t, tw0, tw1, gs);
+        xform<N, WG, PRE, false, TWR>(a, lds, r, t, tw, gs);
         if constexpr (MID == MID_EXPIV) {
 #pragma unroll
             for (int h = 0; h < NR; h++)
@@ -487,14 +505,14 @@ __global__ __launch_bounds__(WG) void k_pass(PassArgs A)
             for (int h = 0; h < NR; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) b[h][l] = in1[rbase[h] + t + T * l];
-            xform<N, WG, PRE, true>(b, lds, r, t, tw0, tw1, gs);
+            xform<N, WG, PRE, true, TWR>(b, lds, r, t, tw, gs);
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], b[h][l]); // f0 = t, f1 = psi
         }
     }
-    xform<N, WG, POST, (PRE != XF_NONE)>(a, lds, r, t, tw0, tw1, gs);
+    xform<N, WG, POST, (PRE != XF_NONE), TWR>(a, lds, r, t, tw, gs);
 
     if constexpr (!STORE_T) {
 #pragma unroll
