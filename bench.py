@@ -62,7 +62,7 @@ def main():
     fdes_amd.consistent(hp)
     def timed_run(skip_empty):
         """K timed steps on a fresh engine/plan; returns (seconds, plan, engine, loop_ms, loop_slices, fft_ms, fft_n, finite)."""
-        eng = fdes_amd.Engine(local, fft=args.fft, probe_stride=args.probe_stride, lanes=args.lanes,
+        eng = fdes_amd.Engine(local, fft=args.fft, probe_stride=0, lanes=args.lanes,
                               pass_threads=args.pass_threads, skip_empty=skip_empty)
         plan = eng.plan(hp, atoms)
 
@@ -90,7 +90,19 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         loop_ms, loop_slices = plan.slice_loop_ms()
+        # roofline leg: one more configuration on lane 0 with the other lanes idle, every `probe_stride`-th launch of the
+        # dominant kernel bracketed by HIP events on the engine's stream.  (Inside the timed region two lanes share the
+        # chip: an event pair there spans the wait for the other lane's kernel as well as the execution, and would not
+        # agree with the profiler's kernel durations.)
+        plan.probe_ms()
+        eng.set_option("lanes_active", 1)
+        eng.set_option("probe_stride", args.probe_stride)
+        plan.run_config(0, 2000 + rank, 0.0)
+        plan.sync()
         fft_ms, fft_n = plan.probe_ms()
+        eng.set_option("probe_stride", 0)
+        eng.set_option("lanes_active", 0)
+        plan.slice_loop_ms()
         # after the timed region: one all-reduce of the partial intensity sums, then the detector chain
         if world > 1:
             ptr, nbytes = plan.intensity_ptr()
@@ -123,15 +135,13 @@ def main():
             # one rocFFT 2-D C2C = 2 passes x (8 B read + 8 B write) per pixel ("FFT pass 16 B/px")
             kname, alg_bytes = f"rocFFT 2-D C2C {m}x{m} (row + column kernels)", 32.0 * px
         ach = alg_bytes / per_launch_s / 1e9
-        lanes = plan.lanes()
         traffic = pmc_traffic(m) if fused else None
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
                 "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": int(fft_n),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                # `lanes` configurations run on their own streams: kernels of different lanes share the chip, so a
-                # launch takes longer than it would alone while `lanes` of them progress at once
-                "concurrent_streams": lanes, "achieved_all_streams": round(ach * lanes, 1)}
+                "timed": "HIP events around every %d-th launch during one configuration run on lane 0 right after the "
+                         "timed steps (other lanes idle)" % args.probe_stride}
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline:
         cpu = cpu_baseline(hp, atoms, m)
@@ -156,8 +166,11 @@ def main():
                        "wave": [m, m], "slices": m3, "atoms": atoms.n, "configs_per_step": world,
                        "parallelism": f"configs sharded over {world} GPU(s)"},
             "lanes": plan.lanes(), "skip_empty": args.skip_empty,
-            # SURVEY 8d "full FDES step" figure (176 + 56 nZ) B/px per slice at the measured whole-GPU rate
-            "full_step_algorithmic_GBps": round((176 + 56 * 1) * px * (value / world) / 1e9, 1),
+            # bytes the fused loop really moves per pixel and slice (P1'/2 + P2/2 + P3 + P4 + P5 + P6 =
+            # 4 + 10 + 16 + 16 + 24 + 24) at the measured rate, and the same rate priced with SURVEY 8d's model of
+            # separate FFT passes ((176 + 56 nZ) B/px: can exceed the HBM peak because the fused loop moves 2.5x less)
+            "engine_bytes_per_px_slice": 94, "engine_GBps": round(94 * px * (value / world) / 1e9, 1),
+            "survey_full_step_model_GBps": round((176 + 56 * 1) * px * (value / world) / 1e9, 1),
             "lane_slice_loop_ms_per_slice": round(loop_ms / max(loop_slices, 1), 5),
             "slice_loop": "fused LDS passes" if fused else "rocFFT + point-wise kernels",
             "roofline": roof, "cpu_baseline": cpu, "finite": finite,

@@ -36,6 +36,7 @@ struct fdes_ctx {
     uint32_t seed = 1; // src/crystalMaker.cu:292
     bool is_lane_ctx = false;
     int skip_empty = 1;   // slices without atoms: t = 1, only the Fresnel step is applied (fused loop)
+    int lanes_active = 0; // > 0: run_config only deals to the first n lanes (bench: time a kernel without a co-running lane)
     int lanes = 2;        // configurations in flight at once (own stream + buffers each) in the fused slice loop
     int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
@@ -75,6 +76,7 @@ struct fdes_plan {
     std::vector<fdes_ctx*> lane_ctx;
     std::vector<hipEvent_t> lane_ev;
     bool is_lane = false;
+    fdes_ctx* parent_ctx = nullptr;    // lanes follow the runtime options (probe_stride) of the context that owns the plan
     unsigned rr = 0;                    // round-robin lane selector
     bool lanes_dirty = false;           // lanes hold partial sums not yet folded into lane 0
     std::vector<int> seg_h;             // host copy of the (slice, species) segment table of the current configuration
@@ -294,7 +296,8 @@ int fused_slice(fdes_plan* pl, int s)
     HIPCHK(c, lds_pass(m1, XF_INV, MID_MULPSI, XF_FWD, true, a5, c->stream));
     PassArgs a6 = pass_y(pl);
     a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->PSIH;
-    const bool probe = c->probe_stride > 0 && (pl->fft_calls++ % (uint64_t)c->probe_stride) == 0;
+    const int pstride = pl->parent_ctx ? pl->parent_ctx->probe_stride : c->probe_stride;
+    const bool probe = pstride > 0 && (pl->fft_calls++ % (uint64_t)pstride) == 0;
     EvPair* ev = nullptr;
     if (probe) {
         if (pl->probe_used == pl->probe.size()) {
@@ -476,6 +479,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
     if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 256 && value != 512) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "skip_empty")) { c->skip_empty = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "lanes")) { if (value < 1 || value > 4) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "probe_stride")) { c->probe_stride = (int)value; return FDES_OK; }
@@ -638,6 +642,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             int lrc = fdes_plan_create(lc, p_in, a, &lp);
             if (lrc != FDES_OK) { c->err = "lane plan: " + lc->err; fdes_plan_destroy(pl); return lrc; }
             lp->is_lane = true;
+            lp->parent_ctx = c;
             pl->lanes.push_back(lp);
             hipEvent_t ev;
             PLHIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -667,7 +672,9 @@ int fdes_plan_run_config(fdes_plan* pl, int k, int j, float weight)
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     if (!pl->lanes.empty()) {
-        const unsigned lane = pl->rr++ % (unsigned)(pl->lanes.size() + 1);
+        unsigned nl = (unsigned)(pl->lanes.size() + 1);
+        if (c->lanes_active > 0 && (unsigned)c->lanes_active < nl) nl = (unsigned)c->lanes_active;
+        const unsigned lane = pl->rr++ % nl;
         if (lane > 0) {
             pl->lanes_dirty = true;
             int rcl = fdes_plan_run_config(pl->lanes[lane - 1], k, j, weight);

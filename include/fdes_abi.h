@@ -202,6 +202,7 @@ int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_
  *   "probe_stride"  see fdes_plan_probe_ms
  *   "skip_empty" 1 (default): a slice that holds no atom has t = 1 exactly, so only its Fresnel step is run
  *                (2 passes instead of 5-6); 0: every slice goes through the full sequence like the reference
+ *   "lanes_active"  n > 0: run_config deals only to the first n lanes from now on (0: all)
  *   "lanes"      1..4 configurations in flight at once in the fused slice loop (default 2): run_config calls are
  *                dealt round-robin to lanes, partial intensity sums are folded in end_measurement
  *   "pass_threads"  0 auto, 256 or 512 threads per LDS-pass workgroup                        */
