@@ -47,15 +47,34 @@ def sub_sliced(hp):
     return q, ratio
 
 
+def emd_available():
+    return bool(abi.load_library().fdes_emd_available())
+
+
+def write_emd(path, hp, atoms=None, image=None, potential=None, exitwave=None, print_level=0):
+    """writeHdf5 (src/rwHdf5.cu:27-1083); image [n3,n2,n1], potential [m3,m2,m1,2], exitwave [n3,m2,m1,2] float32."""
+    f = lambda a: fptr(np.ascontiguousarray(a, np.float32)) if a is not None else None
+    _chk(abi.load_library().fdes_write_emd(str(path).encode(), hp.ptr, atoms.ptr if atoms is not None else None, f(image),
+                                           f(potential), f(exitwave), print_level), str(path))
+
+
+def read_emd(path, skip_atoms=False, capacity=1000):
+    """readHdf5 (src/rwHdf5.cu:1946-2570): returns (HostParams, HostAtoms or None), parameters made consistent."""
+    return _read_file(path, "fdes_read_emd", 2 if skip_atoms else 0, skip_atoms, capacity)
+
+
 def read_cnf(path, bug_compatible=True, skip_atoms=False, capacity=1000):
     """getParams: returns (HostParams, HostAtoms or None). Parameters are made consistent."""
+    return _read_file(path, "fdes_read_cnf", (1 if bug_compatible else 0) | (2 if skip_atoms else 0), skip_atoms, capacity)
+
+
+def _read_file(path, fn, flags, skip_atoms, capacity):
     lib = abi.load_library()
     p = abi.Params()
     _chk(lib.fdes_params_init(C.byref(p), capacity))
     a = abi.Atoms()
-    flags = (1 if bug_compatible else 0) | (2 if skip_atoms else 0)
     try:
-        _chk(lib.fdes_read_cnf(str(path).encode(), C.byref(p), C.byref(a), flags), str(path))
+        _chk(getattr(lib, fn)(str(path).encode(), C.byref(p), C.byref(a), flags), str(path))
         n3 = p.n3
         hp = HostParams(n3)
         ts = np.ctypeslib.as_array(p.tiltspec, (2 * n3,)).copy()

@@ -47,7 +47,9 @@ int main(int argc, char** argv)
     if (print_level < 0 || print_level > 2) { std::fprintf(stderr, "\n printLevel error\n"); return EXIT_FAILURE; }
     if (input.empty()) {
         std::fprintf(stderr, "  confOption is not set, using default configuration\n");
-        input = "dataFDES.cnf"; // then config.emd in the reference (src/FDES.cu:167-188)
+        input = "dataFDES.cnf"; // first dataFDES.cnf, then config.emd (src/FDES.cu:167-188)
+        if (FILE* t = std::fopen(input.c_str(), "rb")) std::fclose(t);
+        else input = "config.emd";
     }
     int rc = fdes_run_file(gpu, print_level, input.c_str(), image.c_str(), emd.c_str(), nullptr, 0, nullptr);
     if (rc) { std::fprintf(stderr, "  FDES failed (%d)\n", rc); return EXIT_FAILURE; }

@@ -143,7 +143,6 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c)
     c = ((k + 1) & 2) ? -c_ : c_;
 }
 
-__device__ __forceinline__ int padi(int i) { return i + (i >> 4); }
 __device__ __forceinline__ int iwc(int i, int m) { return (i > m / 2) ? i - m : i; } // iwCoordIp
 
 constexpr int NR = 2;        // rows per thread (twiddles are shared between them)

@@ -18,11 +18,12 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     if (!input_name) return FDES_EINVAL;
     if (print_level < 0 || print_level > 2) return FDES_EINVAL;
     // dispatch by extension (src/FDES.cu:107-118, src/FDESExport.cu:84-101)
-    if (has_ext(input_name, ".emd") || has_ext(input_name, ".qsc")) {
-        std::fprintf(stderr, "  FDES: input '%s': only .cnf inputs are handled by this build (.emd/.qsc front-ends: INTEGRATION.md)\n", input_name);
+    const bool is_emd = has_ext(input_name, ".emd");
+    if (has_ext(input_name, ".qsc")) {
+        std::fprintf(stderr, "  FDES: input '%s': the QSTEM .qsc front-end is not part of this build (INTEGRATION.md)\n", input_name);
         return FDES_EUNSUPPORTED;
     }
-    if (!has_ext(input_name, ".cnf")) {
+    if (!is_emd && !has_ext(input_name, ".cnf")) {
         std::fprintf(stderr, "  FDES: input file %s: unknown extension\n", input_name);
         return FDES_EINVAL;
     }
@@ -33,7 +34,7 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     const bool external = atomsArray != nullptr; // atomsFromExternal, src/FDESExport.cu:73
     int flags = FDES_CNF_BUG_COMPATIBLE | (external ? FDES_CNF_SKIP_ATOMS : 0);
     if (std::getenv("FDES_STRICT_CNF")) flags &= ~FDES_CNF_BUG_COMPATIBLE;
-    rc = fdes_read_cnf(input_name, &p0, &atoms, flags);
+    rc = is_emd ? fdes_read_emd(input_name, &p0, &atoms, flags) : fdes_read_cnf(input_name, &p0, &atoms, flags);
     if (rc) {
         std::fprintf(stderr, "  FDES: cannot read simulation configuration from %s (%d)\n", input_name, rc);
         fdes_params_release(&p0);
@@ -46,7 +47,10 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     }
     std::fprintf(stderr, "  Number of atoms in the specimen: %i\n", atoms.nAt);
     rc = fdes_params_consistent(&p0);
-    if (rc == FDES_OK) fdes_write_cnf("dataFDES_used.cnf", &p0, &atoms); // src/paramStructure.cu:629-631
+    if (rc == FDES_OK && !is_emd) {
+        fdes_write_cnf("dataFDES_used.cnf", &p0, &atoms);                  // src/paramStructure.cu:629-631
+        (void)fdes_write_emd("config.emd", &p0, &atoms, nullptr, nullptr, nullptr, 0); // src/FDES.cu:213, FDESExport.cu:130
+    }
     std::vector<float> image, potential, exitwave;
     fdes_ctx* ctx = nullptr;
     if (rc == FDES_OK) {

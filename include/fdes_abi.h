@@ -106,6 +106,12 @@ int fdes_write_binary(const char* file, const float* data, size_t n);
 int fdes_write_emd(const char* file, const fdes_params* p, const fdes_atoms* atoms,
                    const float* image, const float* potential, const float* exitwave, int print_level);
 
+/* readHdf5, src/rwHdf5.cu:1946-2570: parameters + atoms from an EMD configuration/result file.  `p` from
+ * fdes_params_init (capacity >= image_size_z); call fdes_params_consistent afterwards.  flags: FDES_CNF_SKIP_ATOMS. */
+int fdes_read_emd(const char* file, fdes_params* p, fdes_atoms* atoms, int flags);
+/* Non-zero when libhdf5 (>= 1.10) could be loaded at run time (FDES_HDF5_LIB overrides the search). */
+int fdes_emd_available(void);
+
 /* ---------------- engine ---------------- */
 
 /* cudaSetDevice(gpu_index), src/FDES.cu:165 */

@@ -254,3 +254,66 @@ def test_sharded_driver_world_size_2_gloo(tmp_path):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == 2
+
+
+# ---------------------------------------------------------------- EMD / HDF5 (SURVEY 8 f-1, f-2 vi)
+EMD_FIXTURE = os.path.join(ROOT, "tests", "golden", "Auparticle_config.emd")
+
+
+@pytest.mark.skipif(not fdes_amd.emd_available(), reason="libhdf5 not loadable")
+def test_read_emd_matches_the_cnf_it_was_written_from():
+    """Reference-produced fixture: Auparticle.emd was written by FDES from dataFDES_Auparticle.cnf (SURVEY KAT 3)."""
+    hp, at = fdes_amd.read_emd(EMD_FIXTURE)
+    c = hp.c
+    assert (c.m1, c.m2, c.m3, c.n1, c.n2, c.n3, c.dn1, c.dn2, c.mode, c.frPh) == (320, 320, 12, 160, 160, 25, 80, 80, 0, 0)
+    assert np.float32(c.E0) == np.float32(50e3) and np.float32(c.pD) == np.float32(100.0)
+    assert np.float32(c.d1) == np.float32(0.25e-10) and np.float32(c.d3) == np.float32(2.1e-10)
+    assert np.float32(c.subSlTh) == np.float32(0.2e-10)
+    # derived constants re-computed by us == the values the reference stored in the file
+    assert np.float32(c.gamma) == np.float32(1.09784758) and np.float32(c.lambda_) == np.float32(5.35530691e-12)
+    assert abs(float(c.sigma) - 12279866.0) <= 1.0
+    assert c.sample_name == b"Gold cuboctahedron" and c.material == b"Au_309" and c.user_name == b"John Smith"
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "au309_atoms.npy"))
+    assert at.n == 309 and np.array_equal(at.Z, ref[:, 0].astype(np.int32)) and np.array_equal(at.xyz, ref[:, 1:4])
+    assert np.array_equal(at.dwf, ref[:, 4]) and np.array_equal(at.occ, ref[:, 5])
+    assert hp.tiltspec.size == 50 and np.float32(hp.tiltspec[0]) == np.float32(-0.17453294)
+
+
+@pytest.mark.skipif(not fdes_amd.emd_available(), reason="libhdf5 not loadable")
+def test_write_emd_round_trip_and_layout(tmp_path):
+    hp, at = S.case_tiny(m=64, m3=3, nz=3, n3=2, tilt=True, beam_tilt=True, frPh=2, pD=3.0)
+    hp.set(sample_name=b"tiny", material=b"AuSiO", comments=b"round trip")
+    fdes_amd.consistent(hp)
+    c = hp.c
+    rng = np.random.default_rng(0)
+    img = rng.random((c.n3, c.n2, c.n1), np.float32)
+    pot = rng.random((c.m3, c.m2, c.m1, 2), np.float32)
+    ew = rng.random((c.n3, c.m2, c.m1, 2), np.float32)
+    out = tmp_path / "results.emd"
+    fdes_amd.write_emd(out, hp, at, img, pot, ew, print_level=2)
+    hp2, at2 = fdes_amd.read_emd(out)
+    for f, _t in abi.Params._fields_:
+        if f in ("tiltspec", "tiltbeam", "defoci", "ab", "cap", "user_name", "institution", "department", "email", "comments",
+                 "sample_name", "material", "nAt"):
+            continue
+        assert getattr(hp.c, f) == getattr(hp2.c, f), f
+    assert hp2.c.nAt == at.n
+    for f, _t in abi.Aberration._fields_:
+        if f in ("C1_1", "C3_1", "C5_1"):
+            continue  # round aberrations carry no angle in the schema
+        assert getattr(hp.c.ab, f) == getattr(hp2.c.ab, f), f
+    assert np.array_equal(hp.tiltspec, hp2.tiltspec) and np.array_equal(hp.tiltbeam, hp2.tiltbeam)
+    assert np.array_equal(hp.defoci, hp2.defoci)
+    assert np.array_equal(at.xyz, at2.xyz) and np.array_equal(at.Z, at2.Z) and np.array_equal(at.occ, at2.occ)
+    assert hp2.c.sample_name == b"tiny" and hp2.c.comments == b"round trip"
+    h5dump = "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):  # data layout: /data/images/data is (n1, n2, n3) with x slowest (src/rwHdf5.cu:413-423)
+        r = subprocess.run([h5dump, "-d", "/data/images/data", "-y", "-w", "0", str(out)], capture_output=True, text=True).stdout
+        body = r[r.index("DATA {") + 6:r.rindex("}")]
+        vals = np.array([float(x) for x in body.replace("}", " ").replace("\n", " ").split(",") if x.strip()], np.float32)
+        assert vals.size == img.size
+        assert np.allclose(vals.reshape(c.n1, c.n2, c.n3), img.transpose(2, 1, 0), rtol=2e-5, atol=1e-6)  # h5dump prints 6 digits
+        names = subprocess.run([h5dump, "-n", str(out)], capture_output=True, text=True).stdout
+        for need in ("/data/potential_slices/data", "/data/exit_wave/dim4", "/imaging/specimen_tilt_x", "/sample/debeye_waller_factors",
+                     "/microscope/aberrations"):
+            assert need in names, need
