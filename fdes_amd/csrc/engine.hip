@@ -35,6 +35,8 @@ struct fdes_ctx {
     int opt_graph = 0;
     uint32_t seed = 1; // src/crystalMaker.cu:292
     bool is_lane_ctx = false;
+    int bench_band = 0;   // fdes_bench_pass only
+    int band_skip = 1;    // do not move / transform the rows and columns the 2/3 band limit zeroes anyway
     int skip_empty = 1;   // slices without atoms: t = 1, only the Fresnel step is applied (fused loop)
     int lanes_active = 0; // > 0: run_config only deals to the first n lanes (bench: time a kernel without a co-running lane)
     int lanes = 2;        // configurations in flight at once (own stream + buffers each) in the fused slice loop
@@ -268,6 +270,11 @@ int fused_slice(fdes_plan* pl, int s)
 {
     fdes_ctx* c = pl->ctx;
     const int m1 = pl->p.m1, m2 = pl->p.m2;
+    // 2/3 band limit: rows/columns whose own frequency index already fails 9 i^2 <= mindim^2 are exact zeros after
+    // P4 (mask) and P6 (masked propagator): P4/P6 run only their live row groups, P3/P5 do not store the rows those
+    // never read, P5 does not load the columns they never write (pre-zeroed at plan creation).
+    const int md = m1 < m2 ? m1 : m2, band = md * md;
+    const int bs = c->band_skip ? 1 : 0;
     auto empty = [&](int q) { return q >= pl->p.m3 || pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ]; };
     const bool have_seg = !pl->seg_h.empty();
     if (have_seg && empty(s)) {
@@ -276,9 +283,11 @@ int fused_slice(fdes_plan* pl, int s)
         PassArgs a5 = pass_x(pl);
         a5.in0 = pl->PSIH; a5.out = pl->F;
         a5.scale = (float)m1; // P5 hands m1 * FFT_x(t psi) to P6 (unnormalised x round trip); exact power of two
+        a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
         HIPCHK(c, lds_pass(m1, XF_NONE, MID_SCALE, XF_NONE, true, a5, c->stream));
         PassArgs a6 = pass_y(pl);
         a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->PSIH;
+        a6.band = band; a6.live_rows_only = bs;
         HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
         pl->slices_skipped++;
         return FDES_OK;
@@ -287,15 +296,19 @@ int fused_slice(fdes_plan* pl, int s)
     if ((s & 1) == 0 || (have_seg && empty(s - 1))) RC(fused_potential_pair(pl, s & ~1));
     PassArgs a3 = pass_x(pl);
     a3.in0 = pl->B; a3.out = pl->C; a3.scale = pl->p.imPot;
+    a3.band = band; a3.skip_dead_stores = bs;
     HIPCHK(c, lds_pass(m1, XF_INV, (s & 1) ? MID_EXPIV_IM : MID_EXPIV_RE, XF_FWD, true, a3, c->stream));
     PassArgs a4 = pass_y(pl);
-    a4.in0 = pl->C; a4.out = pl->E; a4.scale = 1.f / ((float)pl->m12); a4.mindim = m1 < m2 ? m1 : m2;
+    a4.in0 = pl->C; a4.out = pl->E; a4.scale = 1.f / ((float)pl->m12); a4.mindim = md;
+    a4.band = band; a4.live_rows_only = bs;
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, c->stream));
     PassArgs a5 = pass_x(pl);
     a5.in0 = pl->E; a5.in1 = pl->PSIH; a5.out = pl->F;
+    a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
     HIPCHK(c, lds_pass(m1, XF_INV, MID_MULPSI, XF_FWD, true, a5, c->stream));
     PassArgs a6 = pass_y(pl);
     a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->PSIH;
+    a6.band = band; a6.live_rows_only = bs;
     const int pstride = pl->parent_ctx ? pl->parent_ctx->probe_stride : c->probe_stride;
     const bool probe = pstride > 0 && (pl->fft_calls++ % (uint64_t)pstride) == 0;
     EvPair* ev = nullptr;
@@ -322,10 +335,15 @@ int fused_enter(fdes_plan* pl)
     HIPCHK(pl->ctx, lds_pass(pl->p.m1, XF_FWD, MID_NONE, XF_NONE, false, a, pl->ctx->stream));
     return FDES_OK;
 }
-int fused_leave(fdes_plan* pl)
+int fused_leave(fdes_plan* pl, bool propagated)
 {
     PassArgs a = pass_x(pl);
     a.in0 = pl->PSIH; a.out = pl->PSI;
+    if (pl->ctx->band_skip && propagated) { // the dead columns were last written by fused_enter: they count as zero
+        const int md = pl->p.m1 < pl->p.m2 ? pl->p.m1 : pl->p.m2;
+        a.band = md * md;
+        a.skip_dead_loads = 1;
+    }
     a.scale = 1.f / (float)pl->p.m1; // PSIH = FFT_x(psi), unnormalised transforms (m1 is a power of two: exact)
     HIPCHK(pl->ctx, lds_pass(pl->p.m1, XF_INV, MID_SCALE, XF_NONE, false, a, pl->ctx->stream));
     return FDES_OK;
@@ -360,7 +378,7 @@ int slice_loop(fdes_plan* pl, int nslices)
     if (pl->fused) {
         RC(fused_enter(pl));
         for (int s = 0; s < nslices; s++) RC(fused_slice(pl, s));
-        return fused_leave(pl);
+        return fused_leave(pl, nslices > 0);
     }
     for (int s = 0; s < nslices; s++) {
         RC(phase_grating(pl, pl->xyzFP_d, g, s));
@@ -480,6 +498,8 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
     if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 256 && value != 512) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "bench_band")) { c->bench_band = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "skip_empty")) { c->skip_empty = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "lanes")) { if (value < 1 || value > 4) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "probe_stride")) { c->probe_stride = (int)value; return FDES_OK; }
@@ -624,6 +644,8 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         PLCHK(dmalloc(c, &pl->PT, pl->m12));
         PLCHK(dmalloc(c, &pl->GT, pl->m12 * (size_t)pl->nZ));
         PLCHK(dmalloc(c, &pl->bins.rowstart, (size_t)pl->p.m3 * pl->nZ * (size_t)(pl->p.m2 + 1)));
+        // dead (band-limited) rows / columns of these grids are never written again: they must read as zero
+        for (float2* q : {pl->C, pl->E, pl->F, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->m12, c->stream));
         PLHIP(k_build_propagator(pl->PT, pl->kp, 1, c->stream));
         for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 1, c->stream));
     }
@@ -636,7 +658,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             fdes_ctx* lc = nullptr;
             PLCHK(fdes_create(&lc, c->device));
             lc->is_lane_ctx = true;
-            lc->opt_fft = c->opt_fft; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty;
+            lc->opt_fft = c->opt_fft; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip;
             pl->lane_ctx.push_back(lc);
             fdes_plan* lp = nullptr;
             int lrc = fdes_plan_create(lc, p_in, a, &lp);
@@ -966,6 +988,12 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
         A.in0 = a; A.in1 = b; A.out = o; A.zsrc = a; A.gtab = g; A.ptab = pt; A.tw0 = f.tw0x; A.tw1 = f.tw1x; A.nrows = n;
         A.nspecies = 1; A.species_stride = m12; A.scale = 1.f; A.mindim = n;
         A.wg = c->pass_threads == 256 ? 256 : 512;
+        if (c->bench_band) { // micro-benchmark of the band-limit bookkeeping: bit 0 live rows only, bit 1 dead loads, bit 2 dead stores
+            A.band = n * n;
+            A.live_rows_only = (c->bench_band & 1) ? 1 : 0;
+            A.skip_dead_loads = (c->bench_band & 2) ? 1 : 0;
+            A.skip_dead_stores = (c->bench_band & 4) ? 1 : 0;
+        }
         args.push_back(A);
     }
     if (rc == FDES_OK) {

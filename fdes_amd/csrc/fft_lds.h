@@ -42,6 +42,13 @@ struct PassArgs {
     float scale = 1.f;
     int mindim = 0;              // min(m1, m2) for the band limit
     int wg = 512;                // threads per workgroup (512 or 256)
+    // Band limit bookkeeping (band = mindim^2 > 0 enables it): frequency index i is dead iff 9 i^2 > band, i.e. outside
+    // the radial 2/3 mask whatever the other index is.  Dead rows/columns hold exact zeros that nobody needs to move.
+    int band = 0;
+    int band_L = 0;              // largest live |i| (filled in by lds_pass)
+    int live_rows_only = 0;      // the ROWS of this pass are frequencies: only row groups with a live row are launched
+    int skip_dead_loads = 0;     // the COLUMNS of the input are frequencies masked upstream: dead ones are not loaded (= 0)
+    int skip_dead_stores = 0;    // transposed store: output rows (= our columns) that the next pass never reads are not written
     // MID_ATOMS
     const void* recs = nullptr;  // AtomRec[] sorted by (slice, species, row)
     const int* rowstart = nullptr; // [q][nrows + 1]

@@ -144,6 +144,15 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c)
 }
 
 __device__ __forceinline__ int iwc(int i, int m) { return (i > m / 2) ? i - m : i; } // iwCoordIp
+// outside the radial 2/3 band limit for every value of the other index (zeroHighFreq: 9 (i1^2 + i2^2) > mindim^2)
+__host__ __device__ __forceinline__ bool dead_index(int i, int band) { return 9 * i * i > band; }
+// largest |i| that is still live
+inline int live_limit(int band)
+{
+    int L = 0;
+    while (!dead_index(L + 1, band)) L++;
+    return L;
+}
 
 constexpr int NR = 2;        // rows per thread (twiddles are shared between them)
 
@@ -313,8 +322,17 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
         }
     }
     // XCD-aware remap: blocks with equal blockIdx % 8 share an XCD; give them consecutive row groups
-    int bg = (int)blockIdx.x;
-    if ((gridDim.x & 7) == 0) bg = (bg & 7) * ((int)gridDim.x >> 3) + (bg >> 3);
+    int bg;
+    {   // bijective for any grid size: XCD x (= blockIdx % 8) owns a contiguous run of q or q + 1 groups
+        const int nwg = (int)gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+        bg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+    }
+    if (A.live_rows_only) {
+        // live rows are [0, L] and [nrows - L, nrows): the launch covers g_lo low groups, then the groups from g_hi on
+        const int L = A.band_L;
+        const int g_lo = L / R + 1, g_hi = (A.nrows - L) / R;
+        if (bg >= g_lo) bg = g_hi + (bg - g_lo);
+    }
     const int row0 = bg * R;
     // uniform row-group base (scalar registers) + 32-bit per-thread element offsets (< R * N = 16384)
     const size_t gbase = (size_t)row0 * N;
@@ -434,13 +452,36 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
 #pragma unroll
         for (int h = 0; h < NR; h++)
 #pragma unroll
-            for (int l = 0; l < 16; l++) a[h][l] = in0[rbase[h] + t + T * l];
+            for (int l = 0; l < 16; l++) {
+                // branch-free: a dead column re-reads this row's element t (a line that is fetched anyway) and is
+                // zeroed by a select, so the 16 loads still issue back to back and no dead line leaves HBM
+                const int c = t + T * l;
+                const bool dd = A.skip_dead_loads && dead_index(iwc(c, N), A.band);
+                const float2 v = in0[rbase[h] + (dd ? t : c)];
+                a[h][l] = dd ? make_float2(0.f, 0.f) : v;
+            }
         }
         if constexpr (MID == MID_ZSRC) {
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) zsrc[rbase[h] + t + T * l] = make_float2(0.f, 0.f);
+        }
+        // table operands are requested together with the rows (one burst of independent loads) and stay in
+        // registers across the first transform; left at their point of use the compiler issues them one by one
+        float2 pv[(MID == MID_PTAB) ? NR : 1][16];
+        float gvv[(MID == MID_GTAB) ? NR : 1][16];
+        if constexpr (MID == MID_PTAB) {
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) pv[h][l] = ptab[rbase[h] + t + T * l];
+        }
+        if constexpr (MID == MID_GTAB) {
+#pragma unroll
+            for (int h = 0; h < NR; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) gvv[h][l] = gtab[rbase[h] + t + T * l];
         }
         xform<N, WG, PRE, false, TWR>(a, lds, r, t, tw, gs);
         if constexpr (MID == MID_EXPIV) {
@@ -490,20 +531,25 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
             for (int h = 0; h < NR; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
-                    const float gv = gtab[rbase[h] + t + T * l];
+                    const float gv = gvv[h][l];
                     a[h][l] = make_float2(a[h][l].x * gv, a[h][l].y * gv);
                 }
         } else if constexpr (MID == MID_PTAB) {
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
-                for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], ptab[rbase[h] + t + T * l]);
+                for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], pv[h][l]);
         } else if constexpr (MID == MID_MULPSI) {
             float2 b[NR][16];
 #pragma unroll
             for (int h = 0; h < NR; h++)
 #pragma unroll
-                for (int l = 0; l < 16; l++) b[h][l] = in1[rbase[h] + t + T * l];
+                for (int l = 0; l < 16; l++) {
+                    const int c = t + T * l;
+                    const bool dd = A.skip_dead_loads && dead_index(iwc(c, N), A.band);
+                    const float2 v = in1[rbase[h] + (dd ? t : c)];
+                    b[h][l] = dd ? make_float2(0.f, 0.f) : v;
+                }
             xform<N, WG, PRE, true, TWR>(b, lds, r, t, tw, gs);
 #pragma unroll
             for (int h = 0; h < NR; h++)
@@ -537,6 +583,10 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
 #pragma unroll
         for (int it = 0; it < NR * 16; it++) {
             const int c = c0 + it * (WG / R);
+            // wave-uniform: skip an iteration only when every column it covers ([it, it + 1) * WG / R) is dead
+            if (A.skip_dead_stores && dead_index(iwc(it * (WG / R), N), A.band) && dead_index(iwc(it * (WG / R) + WG / R - 1, N), A.band) &&
+                (it * (WG / R) > N / 2) == (it * (WG / R) + WG / R - 1 > N / 2))
+                continue;
             dst[(unsigned)c * ld + (unsigned)rr] = lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))];
         }
     }
@@ -557,7 +607,15 @@ template <int N, int WG, int PRE, int MID, int POST, bool ST> hipError_t launch(
         attr_set = true;
     }
     if (a.nrows % G_::R != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3(a.nrows / G_::R), dim3(WG), lds_bytes, st, a);
+    int groups = a.nrows / G_::R;
+    if (a.live_rows_only) {
+        if (a.band <= 0) return hipErrorInvalidValue;
+        const int L = a.band_L;
+        const int g_lo = L / G_::R + 1, g_hi = (a.nrows - L) / G_::R;
+        if (g_hi > g_lo) groups = g_lo + (a.nrows / G_::R - g_hi); // else: everything is live
+        else { PassArgs b = a; b.live_rows_only = 0; hipLaunchKernelGGL(kern, dim3(groups), dim3(WG), lds_bytes, st, b); return hipGetLastError(); }
+    }
+    hipLaunchKernelGGL(kern, dim3(groups), dim3(WG), lds_bytes, st, a);
     return hipGetLastError();
 }
 
@@ -616,8 +674,10 @@ void lds_fft_twiddles(int n, float* tw0, float* tw1)
         }
 }
 
-hipError_t lds_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
+hipError_t lds_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs& a_in, hipStream_t st)
 {
+    PassArgs a = a_in;
+    if (a.band > 0) a.band_L = live_limit(a.band);
     switch (n) {
     case 256: return dispatch_wg<256>(pre, mid, post, st_t, a, st);
     case 512: return dispatch_wg<512>(pre, mid, post, st_t, a, st);

@@ -206,6 +206,8 @@ int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_
  *   "graph"      1 = replay the slice loop from a hipGraph
  *   "seed"       frozen-phonon seed (reference: 1, src/crystalMaker.cu:292)
  *   "probe_stride"  see fdes_plan_probe_ms
+ *   "band_skip"  1 (default): rows / columns that the radial 2/3 band limit zeroes whatever the other index is are
+ *                neither transformed nor moved in the fused loop (exact: they hold zeros); 0: move everything
  *   "skip_empty" 1 (default): a slice that holds no atom has t = 1 exactly, so only its Fresnel step is run
  *                (2 passes instead of 5-6); 0: every slice goes through the full sequence like the reference
  *   "lanes_active"  n > 0: run_config deals only to the first n lanes from now on (0: all)
