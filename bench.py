@@ -91,7 +91,7 @@ def main():
             dt = float(tmax.item())
         loop_ms, loop_slices = plan.slice_loop_ms()
         # roofline leg: one more configuration on lane 0 with the other lanes idle, every `probe_stride`-th launch of the
-        # dominant kernel bracketed by HIP events on the engine's stream.  (Inside the timed region two lanes share the
+        # dominant kernel (P5) bracketed by HIP events on the engine's stream.  (Inside the timed region two lanes share the
         # chip: an event pair there spans the wait for the other lane's kernel as well as the execution, and would not
         # agree with the profiler's kernel durations.)
         plan.probe_ms()
@@ -128,9 +128,17 @@ def main():
     if fft_n > 0:
         per_launch_s = fft_ms / fft_n * 1e-3
         if fused:
-            # dominant kernel = one LDS row pass; the probed one is P6 (y FFT, * propagator table, y IFFT):
-            # 8 B/px wave in + 8 B/px table in + 8 B/px wave out ("P multiply fused into the IFFT pass")
-            kname, alg_bytes = f"k_pass<{m}, FWD, PTAB, INV, transposed> (P6 of 6 passes/slice)", 24.0 * px
+            # dominant kernel = the longest LDS row pass, P5: rows of t-hat and psi-hat in ([y][kx]), inverse x transforms,
+            # product, forward x transform, transposed store.  The kx columns outside the 2/3 band limit are exact zeros
+            # that are neither loaded nor stored: live = 2 floor(m/3) + 1 of m columns; 8 B in + 8 B in + 8 B out each.
+            L = m // 3
+            while 9 * (L + 1) ** 2 <= m * m:
+                L += 1
+            while 9 * L * L > m * m:
+                L -= 1
+            live = min(m, 2 * L + 1)
+            kname = f"k_pass<{m}, INV, MULPSI, FWD, transposed> (P5 of 6 passes/slice), {live} of {m} kx columns live"
+            alg_bytes = 24.0 * m * live
         else:
             # one rocFFT 2-D C2C = 2 passes x (8 B read + 8 B write) per pixel ("FFT pass 16 B/px")
             kname, alg_bytes = f"rocFFT 2-D C2C {m}x{m} (row + column kernels)", 32.0 * px
@@ -166,10 +174,10 @@ def main():
                        "wave": [m, m], "slices": m3, "atoms": atoms.n, "configs_per_step": world,
                        "parallelism": f"configs sharded over {world} GPU(s)"},
             "lanes": plan.lanes(), "skip_empty": args.skip_empty,
-            # bytes the fused loop really moves per pixel and slice (P1'/2 + P2/2 + P3 + P4 + P5 + P6 =
-            # 4 + 10 + 16 + 16 + 24 + 24) at the measured rate, and the same rate priced with SURVEY 8d's model of
-            # separate FFT passes ((176 + 56 nZ) B/px: can exceed the HBM peak because the fused loop moves 2.5x less)
-            "engine_bytes_per_px_slice": 94, "engine_GBps": round(94 * px * (value / world) / 1e9, 1),
+            # bytes the fused loop moves per pixel and slice (P1'/2 + P2/2 + P3 + P4 + P5 + P6 =
+            # 4 + 10 + 13.3 + 10.7 + 16 + 16, dead band-limit rows/columns not counted) at the measured rate, and the same
+            # rate priced with SURVEY 8d's model of separate FFT passes ((176 + 56 nZ) B/px; may exceed the HBM peak)
+            "engine_bytes_per_px_slice": 70, "engine_GBps": round(70 * px * (value / world) / 1e9, 1),
             "survey_full_step_model_GBps": round((176 + 56 * 1) * px * (value / world) / 1e9, 1),
             "lane_slice_loop_ms_per_slice": round(loop_ms / max(loop_slices, 1), 5),
             "slice_loop": "fused LDS passes" if fused else "rocFFT + point-wise kernels",
@@ -184,13 +192,13 @@ def main():
 
 
 def pmc_traffic(m):
-    """HBM bytes per launch of the probed kernel (P6) from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+    """HBM bytes per launch of the probed kernel (P5) from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE; profiles/r01_pmc_traffic.json).  PMC counters cannot be collected from inside this
     process, so the number is the offline measurement of the same kernel; None for sizes that were not profiled."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
         for k, v in d.items():
-            if k.startswith(f"k_pass<{m},") and k.endswith("1, 6, 2, true>"):
+            if k.startswith(f"k_pass<{m},") and k.endswith("2, 5, 1, true>") and v.get("band_skip", 0) == 1:
                 return v["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass

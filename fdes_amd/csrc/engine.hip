@@ -305,10 +305,7 @@ int fused_slice(fdes_plan* pl, int s)
     PassArgs a5 = pass_x(pl);
     a5.in0 = pl->E; a5.in1 = pl->PSIH; a5.out = pl->F;
     a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
-    HIPCHK(c, lds_pass(m1, XF_INV, MID_MULPSI, XF_FWD, true, a5, c->stream));
-    PassArgs a6 = pass_y(pl);
-    a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->PSIH;
-    a6.band = band; a6.live_rows_only = bs;
+    // roofline probe: P5 is the longest kernel of the loop; every probe_stride-th launch is bracketed by events
     const int pstride = pl->parent_ctx ? pl->parent_ctx->probe_stride : c->probe_stride;
     const bool probe = pstride > 0 && (pl->fft_calls++ % (uint64_t)pstride) == 0;
     EvPair* ev = nullptr;
@@ -322,8 +319,12 @@ int fused_slice(fdes_plan* pl, int s)
         ev = &pl->probe[pl->probe_used++];
         HIPCHK(c, hipEventRecord(ev->a, c->stream));
     }
-    HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
+    HIPCHK(c, lds_pass(m1, XF_INV, MID_MULPSI, XF_FWD, true, a5, c->stream));
     if (ev) HIPCHK(c, hipEventRecord(ev->b, c->stream));
+    PassArgs a6 = pass_y(pl);
+    a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->PSIH;
+    a6.band = band; a6.live_rows_only = bs;
+    HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
     return FDES_OK;
 }
 
@@ -496,7 +497,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "fft")) { if (value < 0 || value > 2) return FDES_EINVAL; c->opt_fft = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
-    if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 256 && value != 512) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_band")) { c->bench_band = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
@@ -634,6 +635,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // 256-thread workgroups (two per CU) measured faster or equal for every pass up to 2048-point rows, with one
         // or two lanes; 4096-point rows keep 512 threads (256 would cut the transposed-store segments to 16 bytes)
         if (c->pass_threads == 512) pl->wg = 512;
+        else if (c->pass_threads == 513 && ok256 && m1 >= 512 && m2 >= 512 && m1 <= 2048 && m2 <= 2048) pl->wg = 513; // 512 threads x 1 row
         else pl->wg = ok256 ? 256 : 512;
         PLCHK(dmalloc(c, &pl->A, pl->m12 * (size_t)pl->nZ));
         PLCHK(dmalloc(c, &pl->B, pl->m12));
@@ -987,7 +989,7 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
         PassArgs A;
         A.in0 = a; A.in1 = b; A.out = o; A.zsrc = a; A.gtab = g; A.ptab = pt; A.tw0 = f.tw0x; A.tw1 = f.tw1x; A.nrows = n;
         A.nspecies = 1; A.species_stride = m12; A.scale = 1.f; A.mindim = n;
-        A.wg = c->pass_threads == 256 ? 256 : 512;
+        A.wg = c->pass_threads == 256 ? 256 : (c->pass_threads == 513 ? 513 : 512);
         if (c->bench_band) { // micro-benchmark of the band-limit bookkeeping: bit 0 live rows only, bit 1 dead loads, bit 2 dead stores
             A.band = n * n;
             A.live_rows_only = (c->bench_band & 1) ? 1 : 0;

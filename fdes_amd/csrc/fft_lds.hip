@@ -154,14 +154,19 @@ inline int live_limit(int band)
     return L;
 }
 
-constexpr int NR = 2;        // rows per thread (twiddles are shared between them)
+// Workgroup geometries (template parameter WG): 256 -> 256 threads x 2 rows per thread, 512 -> 512 threads x 2 rows,
+// 513 -> 512 threads x 1 row per thread (same 4 rows / 68 KiB as 256 at 2048 points, twice the waves per SIMD).
+template <int WG> struct WGeo {
+    static constexpr int THR = (WG == 513) ? 512 : WG;
+    static constexpr int NRV = (WG == 513) ? 1 : 2;
+};
 
 // WG threads per workgroup (512: one workgroup per CU; 256: two per CU, 2 waves per SIMD either way ->
-// 256 VGPRs per lane), each thread owning NR rows x 16 elements.
+// 256 VGPRs per lane), each thread owning WGeo<WG>::NRV rows x 16 elements.
 template <int N, int WG> struct Geo {
     static constexpr int T = N / 16;                 // threads per row
-    static constexpr int R = WG * NR * 16 / N;       // rows per workgroup
-    static constexpr int RH = R / NR;                // rows per "half": thread (r, t) owns rows r and r + RH
+    static constexpr int R = WGeo<WG>::THR * WGeo<WG>::NRV * 16 / N;       // rows per workgroup
+    static constexpr int RH = R / WGeo<WG>::NRV;                // rows per "half": thread (r, t) owns rows r and r + RH
     static constexpr int R3 = N / 256;               // radix of the last stage
     static constexpr int G = (R3 >= 1) ? 16 / R3 : 16;
     static constexpr int LDROW = N + N / 16;         // padded row length in float2
@@ -196,7 +201,7 @@ template <int NW> __device__ __forceinline__ void group_sync(GroupSync& g)
     }
 }
 
-// NR row FFTs at once, data in a[h][16] (a[h][l] = x_h[t + T l] on entry, X_h[t + T l] on exit).
+// WGeo<WG>::NRV row FFTs at once, data in a[h][16] (a[h][l] = x_h[t + T l] on entry, X_h[t + T l] on exit).
 // Stage twiddles either sit in registers for the whole pass (TWR, 60 VGPRs: pays where the kernel stays under 256)
 // or are fetched from the L1/L2-resident tables at the point of use.
 struct Tw {
@@ -205,7 +210,7 @@ struct Tw {
     float2 r0[16], r1[16];
 };
 template <int N, int WG, bool INV, bool WAR0, bool TWR>
-__device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict__ lds, const int r, const int t, const Tw& tw,
+__device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* __restrict__ lds, const int r, const int t, const Tw& tw,
                                         GroupSync& gs)
 {
     using G_ = Geo<N, WG>;
@@ -214,55 +219,55 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
     const int rd0 = t + (t >> 4); // read base: padi(t)
     // ---- stage 0
 #pragma unroll
-    for (int h = 0; h < NR; h++) r16<INV>(a[h]);
+    for (int h = 0; h < WGeo<WG>::NRV; h++) r16<INV>(a[h]);
 #pragma unroll
     for (int k = 1; k < 16; k++) {
         const float2 w = TWR ? tw.r0[k] : tw.g0[k * T + t];
 #pragma unroll
-        for (int h = 0; h < NR; h++) a[h][k] = twmul<INV>(a[h][k], w);
+        for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul<INV>(a[h][k], w);
     }
     if (WAR0) group_sync<NW>(gs);
 #pragma unroll
-    for (int h = 0; h < NR; h++) {
+    for (int h = 0; h < WGeo<WG>::NRV; h++) {
         float2* row = lds + (r + h * G_::RH) * G_::LDROW;
 #pragma unroll
         for (int k = 0; k < 16; k++) row[17 * t + k] = a[h][k]; // padi(16 t + k)
     }
     group_sync<NW>(gs);
 #pragma unroll
-    for (int h = 0; h < NR; h++) {
+    for (int h = 0; h < WGeo<WG>::NRV; h++) {
         const float2* row = lds + (r + h * G_::RH) * G_::LDROW;
 #pragma unroll
         for (int l = 0; l < 16; l++) a[h][l] = row[rd0 + (T + T / 16) * l]; // padi(t + T l): T is a multiple of 16
     }
     // ---- stage 1
 #pragma unroll
-    for (int h = 0; h < NR; h++) r16<INV>(a[h]);
+    for (int h = 0; h < WGeo<WG>::NRV; h++) r16<INV>(a[h]);
     if constexpr (G_::R3 > 1) {
         const int q = t & 15, p = t >> 4;
 #pragma unroll
         for (int k = 1; k < 16; k++) {
             const float2 w = TWR ? tw.r1[k] : tw.g1[k * (T / 16) + p];
 #pragma unroll
-            for (int h = 0; h < NR; h++) a[h][k] = twmul<INV>(a[h][k], w);
+            for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul<INV>(a[h][k], w);
         }
         group_sync<NW>(gs);
 #pragma unroll
-        for (int h = 0; h < NR; h++) {
+        for (int h = 0; h < WGeo<WG>::NRV; h++) {
             float2* row = lds + (r + h * G_::RH) * G_::LDROW;
 #pragma unroll
             for (int k = 0; k < 16; k++) row[q + 272 * p + 17 * k] = a[h][k]; // padi(q + 256 p + 16 k), q < 16
         }
         group_sync<NW>(gs);
 #pragma unroll
-        for (int h = 0; h < NR; h++) {
+        for (int h = 0; h < WGeo<WG>::NRV; h++) {
             const float2* row = lds + (r + h * G_::RH) * G_::LDROW;
 #pragma unroll
             for (int l = 0; l < 16; l++) a[h][l] = row[rd0 + (T + T / 16) * l]; // padi(t + T l): T is a multiple of 16
         }
         // ---- stage 2: G butterflies of radix R3 over registers {i + G j}
 #pragma unroll
-        for (int h = 0; h < NR; h++) {
+        for (int h = 0; h < WGeo<WG>::NRV; h++) {
             if constexpr (G_::R3 == 2) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) r2<INV>(a[h][i], a[h][i + 8]);
@@ -281,19 +286,19 @@ __device__ __forceinline__ void row_fft(float2 (&a)[NR][16], float2* __restrict_
 }
 
 template <int N, int WG, int XF, bool WAR0, bool TWR>
-__device__ __forceinline__ void xform(float2 (&a)[NR][16], float2* lds, int r, int t, const Tw& tw, GroupSync& gs)
+__device__ __forceinline__ void xform(float2 (&a)[WGeo<WG>::NRV][16], float2* lds, int r, int t, const Tw& tw, GroupSync& gs)
 {
     if constexpr (XF == XF_FWD) row_fft<N, WG, false, WAR0, TWR>(a, lds, r, t, tw, gs);
     if constexpr (XF == XF_INV) row_fft<N, WG, true, WAR0, TWR>(a, lds, r, t, tw, gs);
 }
 
 template <int N, int WG, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
+__global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : 2)) void k_pass(PassArgs A)
 {
     using G_ = Geo<N, WG>;
     constexpr int T = G_::T, R = G_::R, RH = G_::RH;
     extern __shared__ float2 lds[];
-    constexpr bool TWR = (MID != MID_MULPSI && MID != MID_PTAB && MID != MID_GTABN);
+    constexpr bool TWR = (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && MID != MID_PTAB && MID != MID_GTABN);
     Tw tw;
     tw.g0 = reinterpret_cast<const float2*>(A.tw0);
     tw.g1 = reinterpret_cast<const float2*>(A.tw1);
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
     gs.cnt = cnts + (NWG > 1 ? threadIdx.x / (64 * NWG) : 0);
     gs.expect = 0;
     if constexpr (NWG > 1) {
-        if (threadIdx.x < WG / 64) cnts[threadIdx.x] = 0;
+        if (threadIdx.x < WGeo<WG>::THR / 64) cnts[threadIdx.x] = 0;
         __syncthreads();
     }
     // (Measured and dropped: letting a workgroup walk several row groups so that a 256-thread kernel leaves one
@@ -336,10 +341,10 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
     const int row0 = bg * R;
     // uniform row-group base (scalar registers) + 32-bit per-thread element offsets (< R * N = 16384)
     const size_t gbase = (size_t)row0 * N;
-    unsigned rbase[NR];
-    int grow[NR];
+    unsigned rbase[WGeo<WG>::NRV];
+    int grow[WGeo<WG>::NRV];
 #pragma unroll
-    for (int h = 0; h < NR; h++) {
+    for (int h = 0; h < WGeo<WG>::NRV; h++) {
         grow[h] = row0 + r + h * RH;
         rbase[h] = (unsigned)((r + h * RH) * N);
     }
@@ -350,23 +355,23 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
     float2* __restrict__ zsrc = A.zsrc ? reinterpret_cast<float2*>(A.zsrc) + gbase : nullptr;
     float2* __restrict__ outn = reinterpret_cast<float2*>(A.out) + gbase;
 
-    float2 a[NR][16];
+    float2 a[WGeo<WG>::NRV][16];
     if constexpr (MID == MID_GTABN) {
         // sum over species in Fourier space, then one inverse transform (phaseGrating's species loop)
-        float2 acc[NR][16];
+        float2 acc[WGeo<WG>::NRV][16];
 #pragma unroll
-        for (int h = 0; h < NR; h++)
+        for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
             for (int l = 0; l < 16; l++) acc[h][l] = make_float2(0.f, 0.f);
         for (int z = 0; z < A.nspecies; z++) {
             const size_t zo = (size_t)z * A.species_stride;
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = in0[zo + rbase[h] + t + T * l];
             xform<N, WG, PRE, true, TWR>(a, lds, r, t, tw, gs);
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
                     const float gv = gtab[zo + rbase[h] + t + T * l];
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
                 }
         }
 #pragma unroll
-        for (int h = 0; h < NR; h++)
+        for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
             for (int l = 0; l < 16; l++) a[h][l] = acc[h][l];
     } else {
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
             // straight into the registers of the threads that own the four pixels.  Every thread walks the same
             // atoms (uniform control flow); contributions are added in sorted order (deterministic).
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = make_float2(0.f, 0.f);
             const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs);
@@ -407,8 +412,8 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
                 // empty row group: its spectrum is zero
                 if constexpr (STORE_T) {
 #pragma unroll
-                    for (int it = 0; it < NR * 16; it++) {
-                        const int e = it * WG + tid;
+                    for (int it = 0; it < WGeo<WG>::NRV * 16; it++) {
+                        const int e = it * WGeo<WG>::THR + tid;
                         (reinterpret_cast<float2*>(A.out) + row0)[(unsigned)(e / R) * (unsigned)A.nrows + (unsigned)(e & (R - 1))] = make_float2(0.f, 0.f);
                     }
                 }
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
                 for (int base = plo[comp]; base < phi[comp]; base += CAP) {
                     const int nb = (phi[comp] - base < CAP) ? phi[comp] - base : CAP;
                     __syncthreads();
-                    for (int i = tid; i < nb; i += WG) sh[i] = recs[base + i];
+                    for (int i = tid; i < nb; i += WGeo<WG>::THR) sh[i] = recs[base + i];
                     __syncthreads();
 #pragma unroll 1
                     for (int p = 0; p < nb; p++) {
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
                             if ((rr % RH) != r || (c % T) != t) continue;
                             const int hh = rr / RH, ll = c / T;
 #pragma unroll
-                            for (int h = 0; h < NR; h++)
+                            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                                 for (int l = 0; l < 16; l++)
                                     if (h == hh && l == ll) { if (comp) a[h][l].y += w; else a[h][l].x += w; }
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
             __syncthreads(); // the staging area becomes the exchange buffer
         } else {
 #pragma unroll
-        for (int h = 0; h < NR; h++)
+        for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
             for (int l = 0; l < 16; l++) {
                 // branch-free: a dead column re-reads this row's element t (a line that is fetched anyway) and is
@@ -463,30 +468,30 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
         }
         if constexpr (MID == MID_ZSRC) {
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) zsrc[rbase[h] + t + T * l] = make_float2(0.f, 0.f);
         }
         // table operands are requested together with the rows (one burst of independent loads) and stay in
         // registers across the first transform; left at their point of use the compiler issues them one by one
-        float2 pv[(MID == MID_PTAB) ? NR : 1][16];
-        float gvv[(MID == MID_GTAB) ? NR : 1][16];
+        float2 pv[(MID == MID_PTAB) ? WGeo<WG>::NRV : 1][16];
+        float gvv[(MID == MID_GTAB) ? WGeo<WG>::NRV : 1][16];
         if constexpr (MID == MID_PTAB) {
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) pv[h][l] = ptab[rbase[h] + t + T * l];
         }
         if constexpr (MID == MID_GTAB) {
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) gvv[h][l] = gtab[rbase[h] + t + T * l];
         }
         xform<N, WG, PRE, false, TWR>(a, lds, r, t, tw, gs);
         if constexpr (MID == MID_EXPIV) {
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
                     const float e = __expf(-a[h][l].y);
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
         } else if constexpr (MID == MID_EXPIV_RE || MID == MID_EXPIV_IM) {
             // two slices share one potential grid: V_s = Re, V_{s+1} = Im; absorption V.y = imPot * V.x
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
                     const float v = (MID == MID_EXPIV_RE) ? a[h][l].x : a[h][l].y;
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
             // threshold is exact and the integer comparison is the same predicate, without 32 divisions per thread.
             const int md2 = A.mindim * A.mindim;
 #pragma unroll
-            for (int h = 0; h < NR; h++) {
+            for (int h = 0; h < WGeo<WG>::NRV; h++) {
                 const int i2 = iwc(grow[h], A.nrows);
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
@@ -523,12 +528,12 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
             }
         } else if constexpr (MID == MID_SCALE) {
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = make_float2(a[h][l].x * A.scale, a[h][l].y * A.scale);
         } else if constexpr (MID == MID_GTAB) {
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
                     const float gv = gvv[h][l];
@@ -536,13 +541,13 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
                 }
         } else if constexpr (MID == MID_PTAB) {
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], pv[h][l]);
         } else if constexpr (MID == MID_MULPSI) {
-            float2 b[NR][16];
+            float2 b[WGeo<WG>::NRV][16];
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
                     const int c = t + T * l;
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
                 }
             xform<N, WG, PRE, true, TWR>(b, lds, r, t, tw, gs);
 #pragma unroll
-            for (int h = 0; h < NR; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], b[h][l]); // f0 = t, f1 = psi
         }
@@ -561,14 +566,14 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
 
     if constexpr (!STORE_T) {
 #pragma unroll
-        for (int h = 0; h < NR; h++)
+        for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
             for (int l = 0; l < 16; l++) outn[rbase[h] + t + T * l] = a[h][l];
     } else {
         // stage the R x N tile as [c][r] (swizzled) and write R contiguous elements per output row
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < NR; h++) {
+        for (int h = 0; h < WGeo<WG>::NRV; h++) {
             const int rr = r + h * RH;
 #pragma unroll
             for (int l = 0; l < 16; l++) {
@@ -581,11 +586,12 @@ __global__ __launch_bounds__(WG, (WG == 256 ? 2 : 2)) void k_pass(PassArgs A)
         const unsigned ld = (unsigned)A.nrows;
         const int rr = tid & (R - 1), c0 = tid / R; // WG is a multiple of R: rr is the same in every iteration
 #pragma unroll
-        for (int it = 0; it < NR * 16; it++) {
-            const int c = c0 + it * (WG / R);
+        for (int it = 0; it < WGeo<WG>::NRV * 16; it++) {
+            const int c = c0 + it * (WGeo<WG>::THR / R);
             // wave-uniform: skip an iteration only when every column it covers ([it, it + 1) * WG / R) is dead
-            if (A.skip_dead_stores && dead_index(iwc(it * (WG / R), N), A.band) && dead_index(iwc(it * (WG / R) + WG / R - 1, N), A.band) &&
-                (it * (WG / R) > N / 2) == (it * (WG / R) + WG / R - 1 > N / 2))
+            if (A.skip_dead_stores && dead_index(iwc(it * (WGeo<WG>::THR / R), N), A.band) &&
+                dead_index(iwc(it * (WGeo<WG>::THR / R) + WGeo<WG>::THR / R - 1, N), A.band) &&
+                (it * (WGeo<WG>::THR / R) > N / 2) == (it * (WGeo<WG>::THR / R) + WGeo<WG>::THR / R - 1 > N / 2))
                 continue;
             dst[(unsigned)c * ld + (unsigned)rr] = lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))];
         }
@@ -613,9 +619,9 @@ template <int N, int WG, int PRE, int MID, int POST, bool ST> hipError_t launch(
         const int L = a.band_L;
         const int g_lo = L / G_::R + 1, g_hi = (a.nrows - L) / G_::R;
         if (g_hi > g_lo) groups = g_lo + (a.nrows / G_::R - g_hi); // else: everything is live
-        else { PassArgs b = a; b.live_rows_only = 0; hipLaunchKernelGGL(kern, dim3(groups), dim3(WG), lds_bytes, st, b); return hipGetLastError(); }
+        else { PassArgs b = a; b.live_rows_only = 0; hipLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, b); return hipGetLastError(); }
     }
-    hipLaunchKernelGGL(kern, dim3(groups), dim3(WG), lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, a);
     return hipGetLastError();
 }
 
@@ -647,13 +653,14 @@ template <int N, int WG> hipError_t dispatch(int pre, int mid, int post, bool st
 template <int N> hipError_t dispatch_wg(int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
 {
     if (a.wg == 256) return dispatch<N, 256>(pre, mid, post, st_t, a, st);
+    if constexpr (N >= 512 && N <= 2048) { if (a.wg == 513) return dispatch<N, 513>(pre, mid, post, st_t, a, st); }
     return dispatch<N, 512>(pre, mid, post, st_t, a, st);
 }
 
 } // namespace
 
 bool lds_fft_supported_len(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
-int lds_fft_rows_per_block(int n, int wg) { return (wg == 256 ? 256 : 512) * NR * 16 / n; }
+int lds_fft_rows_per_block(int n, int wg) { return (wg == 256 ? 256 * 2 : (wg == 513 ? 512 * 1 : 512 * 2)) * 16 / n; }
 
 void lds_fft_twiddles(int n, float* tw0, float* tw1)
 {
