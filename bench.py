@@ -48,9 +48,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # FDES_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer GPUs than ranks (ranks share devices, reductions go
+    # through host memory); the default is RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("FDES_BENCH_BACKEND", "nccl")
+    ngpu = max(torch.cuda.device_count(), 1)
+    if backend != "nccl":
+        local = local % ngpu
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
 
     import fdes_amd
@@ -86,7 +95,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            tmax = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         loop_ms, loop_slices = plan.slice_loop_ms()
@@ -108,7 +117,12 @@ def main():
             ptr, nbytes = plan.intensity_ptr()
             buf = torch.empty(nbytes // 4, device="cuda", dtype=torch.float32)
             plan.copy_intensity(buf.data_ptr(), 0)
-            dist.all_reduce(buf)
+            if backend == "nccl":
+                dist.all_reduce(buf)
+            else:
+                hb = buf.cpu()
+                dist.all_reduce(hb)
+                buf.copy_(hb)
             torch.cuda.synchronize()
             plan.copy_intensity(buf.data_ptr(), 1)
         plan.end_measurement(0)
