@@ -12,7 +12,7 @@ BYTES = {(0, 0, 0, 0): 16, (0, 0, 0, 1): 16, (1, 0, 0, 0): 16, (1, 0, 0, 1): 16,
 for n in [int(x) for x in (sys.argv[1:] or ["2048"])]:
     for key, name in NAMES.items():
         row = f"n={n:5d} {name:22s}"
-        for wg, lp in ((256, 1), (513, 1)):
+        for wg, lp in ((256, 1), (512, 1)):
             for ns in (1, 2):
                 eng.set_option("pass_threads", wg)
                 try:
