@@ -63,6 +63,11 @@ def read_emd(path, skip_atoms=False, capacity=1000):
     return _read_file(path, "fdes_read_emd", 2 if skip_atoms else 0, skip_atoms, capacity)
 
 
+def read_qsc(path, skip_atoms=False, capacity=1000):
+    """readQsc (src/rwQsc.cu:8-1101): QSTEM .qsc + the .cfg cell it names -> (HostParams, HostAtoms or None)."""
+    return _read_file(path, "fdes_read_qsc", 2 if skip_atoms else 0, skip_atoms, capacity)
+
+
 def read_cnf(path, bug_compatible=True, skip_atoms=False, capacity=1000):
     """getParams: returns (HostParams, HostAtoms or None). Parameters are made consistent."""
     return _read_file(path, "fdes_read_cnf", (1 if bug_compatible else 0) | (2 if skip_atoms else 0), skip_atoms, capacity)

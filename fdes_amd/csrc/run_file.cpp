@@ -19,11 +19,8 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     if (print_level < 0 || print_level > 2) return FDES_EINVAL;
     // dispatch by extension (src/FDES.cu:107-118, src/FDESExport.cu:84-101)
     const bool is_emd = has_ext(input_name, ".emd");
-    if (has_ext(input_name, ".qsc")) {
-        std::fprintf(stderr, "  FDES: input '%s': the QSTEM .qsc front-end is not part of this build (INTEGRATION.md)\n", input_name);
-        return FDES_EUNSUPPORTED;
-    }
-    if (!is_emd && !has_ext(input_name, ".cnf")) {
+    const bool is_qsc = !is_emd && !has_ext(input_name, ".cnf") && has_ext(input_name, ".qsc");
+    if (!is_emd && !is_qsc && !has_ext(input_name, ".cnf")) {
         std::fprintf(stderr, "  FDES: input file %s: unknown extension\n", input_name);
         return FDES_EINVAL;
     }
@@ -34,7 +31,9 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     const bool external = atomsArray != nullptr; // atomsFromExternal, src/FDESExport.cu:73
     int flags = FDES_CNF_BUG_COMPATIBLE | (external ? FDES_CNF_SKIP_ATOMS : 0);
     if (std::getenv("FDES_STRICT_CNF")) flags &= ~FDES_CNF_BUG_COMPATIBLE;
-    rc = is_emd ? fdes_read_emd(input_name, &p0, &atoms, flags) : fdes_read_cnf(input_name, &p0, &atoms, flags);
+    rc = is_emd   ? fdes_read_emd(input_name, &p0, &atoms, flags)
+         : is_qsc ? fdes_read_qsc(input_name, &p0, &atoms, flags)
+                  : fdes_read_cnf(input_name, &p0, &atoms, flags);
     if (rc) {
         std::fprintf(stderr, "  FDES: cannot read simulation configuration from %s (%d)\n", input_name, rc);
         fdes_params_release(&p0);
@@ -48,7 +47,7 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     std::fprintf(stderr, "  Number of atoms in the specimen: %i\n", atoms.nAt);
     rc = fdes_params_consistent(&p0);
     if (rc == FDES_OK && !is_emd) {
-        fdes_write_cnf("dataFDES_used.cnf", &p0, &atoms);                  // src/paramStructure.cu:629-631
+        fdes_write_cnf(is_qsc ? "ParamsUsedQsc.txt" : "dataFDES_used.cnf", &p0, &atoms); // src/paramStructure.cu:629-631, src/rwQsc.cu:1097
         (void)fdes_write_emd("config.emd", &p0, &atoms, nullptr, nullptr, nullptr, 0); // src/FDES.cu:213, FDESExport.cu:130
     }
     std::vector<float> image, potential, exitwave;

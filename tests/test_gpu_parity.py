@@ -267,3 +267,30 @@ def test_shipped_au309_example_through_the_cli(oracle, tmp_path):
     if fdes_amd.emd_available():
         hp2, at2 = fdes_amd.read_emd(tmp_path / "results.emd")
         assert hp2.c.n3 == 25 and at2.n == 309
+
+
+def test_srtio3_qsc_through_the_cli(oracle, tmp_path):
+    """SURVEY C1 as a QSTEM input: SrTiO3.cfg (the reference's bin/SrTiO3.cfg) replicated 3x3x4 by the .qsc
+    front-end, nx = 128 -> 256^2 wave, 8 slices of 1.9525 A cut into 80 sub-slices (subSlTh = d3/10,
+    src/rwQsc.cu:953), imaging mode with objective aperture; FDES CLI -> ParamsUsedQsc.txt, Measurements.bin."""
+    import shutil
+    import subprocess
+    shutil.copy(os.path.join(G, "qsc", "SrTiO3.cfg"), tmp_path / "SrTiO3.cfg")
+    (tmp_path / "c1.qsc").write_text(
+        "mode: TEM\nfilename: SrTiO3.cfg\nNCELLX: 3\nNCELLY: 3\nNCELLZ: 4\nv0: 200\ntds: no\n"
+        "slice-thickness: 1.9525\nslices: 8\nnx: 128\nCs: 0.05\nalpha: 15\ndefocus: 13.7\n"
+        "cal_mode: 0\nobjective_aperture: 20e-3\nabsorptive_potential_factor: 0.1\npixel_dose: 0\n")
+    exe = os.path.abspath(os.path.join(os.path.dirname(G), "..", "fdes_amd", "csrc", "FDES"))
+    r = subprocess.run([exe, "--input_name", "c1.qsc", "--image_name", "Measurements.bin", "--emd_name", "results.emd"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    hp, at = fdes_amd.read_qsc(tmp_path / "c1.qsc")
+    assert (hp.c.m1, hp.c.m2, hp.c.m3, at.n) == (256, 256, 8, 180)
+    used, at_used = fdes_amd.read_cnf(tmp_path / "ParamsUsedQsc.txt", bug_compatible=False)
+    assert (used.c.m1, used.c.m3, at_used.n) == (256, 8, 180) and abs(used.c.subSlTh / hp.c.subSlTh - 1) < 1e-6
+    img = np.fromfile(tmp_path / "Measurements.bin", np.float32).reshape(1, 128, 128)
+    ref = oracle.build_measurements(hp, at, prec="f64")["image"]
+    err = np.abs(img - ref).max() / np.abs(ref).max()
+    print("[parity] SrTiO3 .qsc CLI vs f64 oracle: max rel err", err, "contrast", ref.std() / ref.mean())
+    assert ref.std() / ref.mean() > 1e-3      # a non-trivial image
+    assert err < 2e-4

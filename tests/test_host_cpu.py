@@ -317,3 +317,148 @@ def test_write_emd_round_trip_and_layout(tmp_path):
         for need in ("/data/potential_slices/data", "/data/exit_wave/dim4", "/imaging/specimen_tilt_x", "/sample/debeye_waller_factors",
                      "/microscope/aberrations"):
             assert need in names, need
+
+
+# ---------------------------------------------------------------------------------------------------
+# .qsc front-end: src/rwQsc.cu + qstem-libs readparam / .cfg reader / replicateUnitCell
+QSC = os.path.join(ROOT, "tests", "golden", "qsc")   # the reference's bin/test.qsc + bin/SrTiO3.cfg (data fixtures)
+
+
+def _srtio3_supercell(ncx, ncy, ncz, a=3.905):
+    """Independent numpy restatement of the atom list readQsc hands to buildMeasurements for an orthogonal
+    cell without tilt: unit-cell atoms sorted by (z, y, x), index = (icz + icy*ncz + icx*ncy*ncz)*5 + i,
+    cartesian = a*(frac + cell), minus the box corner (0), x1e-10, minus (max-min)/2 per axis."""
+    cell = [(38, 0, 0, 0, 0.6214), (22, .5, .5, .5, 0.4390), (8, 0, .5, .5, 0.7323), (8, .5, 0, .5, 0.7323), (8, .5, .5, 0, 0.7323)]
+    cell.sort(key=lambda t: (t[3], t[2], t[1]))
+    Z = np.zeros(5 * ncx * ncy * ncz, np.int32)
+    xyz = np.zeros((Z.size, 3), np.float32)
+    dwf = np.zeros(Z.size, np.float32)
+    for i, (z, fx, fy, fz, dw) in enumerate(cell):
+        for icx in range(ncx):
+            for icy in range(ncy):
+                for icz in range(ncz):
+                    j = (icz + icy * ncz + icx * ncy * ncz) * 5 + i
+                    Z[j] = z
+                    frac = np.float32([fx, fy, fz]) + np.float32([icx, icy, icz])
+                    xyz[j] = (a * frac.astype(np.float64)).astype(np.float32)
+                    dwf[j] = np.float32(np.float64(np.float32(dw)) * 1e-20)
+    xyz = (xyz.astype(np.float64) * 1e-10).astype(np.float32)
+    lo = np.minimum(xyz.min(0), np.float32(1))
+    hi = np.maximum(xyz.max(0), np.float32(0))
+    return Z, xyz - (hi - lo) / np.float32(2), dwf
+
+
+def test_read_qsc_shipped_example():
+    """bin/test.qsc: 9x9x20 SrTiO3 cells, nx = 400 -> m = 800, 40 slices of 1.9525 A -> subSlTh = d3/10, CBED."""
+    hp, at = fdes_amd.read_qsc(os.path.join(QSC, "test.qsc"))
+    c = hp.c
+    assert (c.n1, c.n2, c.dn1, c.dn2, c.m1, c.m2, c.m3, c.n3) == (400, 400, 200, 200, 800, 800, 40, 1)
+    f32 = np.float32
+    assert c.d1 == f32(np.float64(f32(0.087862)) * 1e-10) and c.d2 == c.d1
+    assert c.d3 == f32(np.float64(f32(1.9525)) * 1e-10)
+    assert c.subSlTh == f32(np.float64(f32(1.9525)) * 1e-10 / 10)
+    assert c.E0 == f32(200e3) and c.illangle == f32(np.float64(f32(15)) / 1e3)
+    assert c.mode == 2 and c.pD == f32(10) and c.ObjAp == f32(20e-3) and c.imPot == f32(0.1) and c.frPh == 0
+    assert c.defocspread == f32(1e-9) and (c.mtfa, c.mtfb, c.mtfc) == (1, 0, 0)
+    cs_A = f32(np.float64(f32(0.05)) * 1e7)
+    assert c.ab.C3_0 == f32(np.float64(cs_A) * 1e-10)
+    assert c.ab.C1_0 == f32(np.float64(f32(10.0 * np.float64(f32(13.7)))) * 1e-10)
+    assert c.ab.C5_0 == 0 and c.ab.A1_0 == 0 and c.ab.A1_1 == 0
+    assert c.tilt_offset_x == 0 and hp.tiltbeam[0] == 0 and hp.tiltbeam[1] == 0
+    assert c.material == b"SrTiO3" and c.sample_name == b"SrTiO3_CELL_09_09_20"
+    assert abs(c.lambda_ - 2.5079e-12) < 1e-15          # made consistent
+    Z, xyz, dwf = _srtio3_supercell(9, 9, 20)
+    assert at.n == 8100 and c.nAt == 8100
+    assert np.array_equal(at.Z, Z)
+    assert np.array_equal(at.xyz, xyz)                   # bit-exact
+    assert np.array_equal(at.dwf, dwf) and np.all(at.occ == 1)
+    q, ratio = fdes_amd.sub_sliced(hp)
+    assert ratio == 10 and q.c.m3 == 400
+
+
+_QSC_MIN = """mode: {mode}
+filename: {cfg}
+NCELLX: 2
+NCELLY: 3
+NCELLZ: {ncz}
+{extra}
+nx: 32
+v0: 80
+Cs: 1.2
+alpha: 0.5
+"""
+
+
+def _write_qsc(tmp_path, mode="TEM", cfg="SrTiO3.cfg", ncz="2", extra=""):
+    import shutil
+    shutil.copy(os.path.join(QSC, "SrTiO3.cfg"), tmp_path / "SrTiO3.cfg")
+    p = tmp_path / "t.qsc"
+    p.write_text(_QSC_MIN.format(mode=mode, cfg=cfg, ncz=ncz, extra=extra))
+    return p
+
+
+def test_read_qsc_defaults_and_quirks(tmp_path):
+    # no resolution -> super-cell / nx; no slice-thickness -> c / slices; ny = nx; Scherzer defocus; "STEM" contains "TEM"
+    p = _write_qsc(tmp_path, mode="STEM", extra="slices: 4\nBeam tilt X: 2 deg\nBeam tilt Y: 3\nCrystal tilt Z: 0.25")
+    hp, at = fdes_amd.read_qsc(p)
+    c = hp.c
+    f32 = np.float32
+    assert (c.n1, c.n2, c.m1, c.m3) == (32, 32, 64, 4) and at.n == 5 * 2 * 3 * 2
+    # rotated about z by 0.25 rad: the bounding box of the 2x3 cell footprint sets ax, by
+    w, h = 2 * 3.905, 3 * 3.905
+    ax = w * np.cos(0.25) + h * np.sin(0.25)
+    assert abs(c.d1 - ax / 32 * 1e-10) < 1e-17
+    assert abs(c.d3 - 2 * 3.905 / 4 * 1e-10) < 1e-17 and abs(c.subSlTh - c.d3 / 10) < 1e-18
+    assert hp.tiltbeam[0] == f32(np.float64(f32(2)) * (3.1415926535897 / 180.0)) and hp.tiltbeam[1] == f32(3)
+    assert c.tilt_offset_z == f32(0.25) and c.tilt_offset_x == 0
+    lam = 12.3984244 / np.sqrt(80.0 * (2 * 510.99906 + 80.0))
+    cs_A = f32(np.float64(f32(1.2)) * 1e7)
+    df = -f32(np.sqrt(1.5 * np.float64(cs_A) * lam))
+    assert c.ab.C1_0 == f32(np.float64(df) * 1e-10)
+    # rotation about the box centre keeps the centroid of the (centred) atom cloud on the axis
+    Z0, xyz0, _ = _srtio3_supercell(2, 3, 2)
+    assert np.array_equal(at.Z, Z0)
+    r0 = np.hypot(*(xyz0[:, :2] - xyz0[:, :2].mean(0)).T)
+    r1 = np.hypot(*(at.xyz[:, :2] - at.xyz[:, :2].mean(0)).T)
+    assert np.allclose(r0, r1, atol=2e-16) and np.allclose(at.xyz[:, 2], xyz0[:, 2], atol=1e-17)
+    # skip_atoms mirrors atomsFromExternal
+    hp2, none = fdes_amd.read_qsc(p, skip_atoms=True)
+    assert none is None and hp2.c.m1 == 64
+
+
+def test_read_qsc_slices_from_thickness_and_celldiv(tmp_path):
+    p = _write_qsc(tmp_path, ncz="4/2", extra="slice-thickness: 1.0\ndefocus: 5\nastigmatism: 2\nC5: 1")
+    hp, at = fdes_amd.read_qsc(p)
+    # slices = int(c / (cellDiv * thickness) + 0.99) with c = 4 cells.  (A "center slices:" line without a
+    # "slices:" line would be picked up by the substring search for "slices:" — undefined in the reference.)
+    assert hp.c.m3 == int(np.float32(4 * 3.905) / (2 * 1.0) + 0.99)
+    assert hp.c.ab.C1_0 == np.float32(np.float64(np.float32(50.0)) * 1e-10)
+    assert hp.c.ab.A1_0 == np.float32(np.float64(np.float32(20.0)) * 1e-9)      # the reference's unit slip, kept
+    assert hp.c.ab.C5_0 == np.float32(np.float64(np.float32(np.float64(np.float32(1)) * 1e7)) * 1e-3)
+
+
+@pytest.mark.parametrize("kw, code", [
+    (dict(mode="CBED"), -5), (dict(extra="tds: yes"), -5), (dict(extra="Cube: 10 10 10"), -5),
+    (dict(cfg="missing.cfg"), -2), (dict(cfg="cell.cssr"), -5)])
+def test_read_qsc_rejects_what_it_does_not_carry_over(tmp_path, kw, code):
+    p = _write_qsc(tmp_path, **kw)
+    with pytest.raises(fdes_amd.FdesError) as e:
+        fdes_amd.read_qsc(p)
+    assert e.value.code == code
+
+
+def test_read_qsc_needs_the_keys_the_reference_exits_on(tmp_path):
+    for key in ("nx:", "v0:", "Cs:", "alpha:", "filename:", "mode:"):
+        p = _write_qsc(tmp_path)
+        p.write_text("".join(l for l in p.read_text().splitlines(True) if not l.startswith(key)))
+        with pytest.raises(fdes_amd.FdesError):
+            fdes_amd.read_qsc(p)
+
+
+def test_cfg_reader_partial_occupancy_is_refused(tmp_path):
+    p = _write_qsc(tmp_path)
+    cfg = (tmp_path / "SrTiO3.cfg").read_text().replace("0.5 0.5 0.5  0.4390  1.0", "0.5 0.5 0.5  0.4390  0.5")
+    (tmp_path / "SrTiO3.cfg").write_text(cfg)
+    with pytest.raises(fdes_amd.FdesError) as e:
+        fdes_amd.read_qsc(p)
+    assert e.value.code == -5
