@@ -36,6 +36,8 @@ struct fdes_ctx {
     uint32_t seed = 1; // src/crystalMaker.cu:292
     bool is_lane_ctx = false;
     int bench_band = 0;   // fdes_bench_pass only
+    float2* share_PT = nullptr; // lane contexts: tables owned by the parent plan
+    float* share_GT = nullptr;
     int band_skip = 1;    // do not move / transform the rows and columns the 2/3 band limit zeroes anyway
     int skip_empty = 1;   // slices without atoms: t = 1, only the Fresnel step is applied (fused loop)
     int lanes_active = 0; // > 0: run_config only deals to the first n lanes (bench: time a kernel without a co-running lane)
@@ -85,6 +87,7 @@ struct fdes_plan {
     int64_t slices_skipped = 0;
     float2 *A = nullptr, *B = nullptr, *C = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
     float* GT = nullptr;
+    bool tables_shared = false; // PT / GT belong to the parent plan (lanes)
     std::vector<EvPair> probe;
     size_t probe_used = 0;
     uint64_t fft_calls = 0;
@@ -519,7 +522,8 @@ int fdes_plan_destroy(fdes_plan* pl)
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {pl->Z_d, pl->spec_d, pl->xyz0_d, pl->xyzTO_d, pl->xyzK_d, pl->xyzFP_d, pl->dwf_d, pl->occ_d, pl->bins.keys,
                     pl->bins.keys_sorted, pl->bins.vals, pl->bins.order, pl->bins.seg, pl->bins.tmp, pl->bins.recs, pl->bins.recs_sorted, pl->bins.rowstart, pl->D, pl->VH, pl->T, pl->PSI,
-                    pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A, pl->B, pl->C, pl->E, pl->F, pl->PSIH, pl->PT, pl->GT};
+                    pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A == pl->C ? nullptr : pl->A, pl->B, pl->C, pl->E, pl->PSIH,
+                    pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT}; // F aliases C
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (auto& e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : pl->probe) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -637,19 +641,30 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         if (c->pass_threads == 512) pl->wg = 512;
         else if (c->pass_threads == 513 && ok256 && m1 >= 512 && m2 >= 512 && m1 <= 2048 && m2 <= 2048) pl->wg = 513; // 512 threads x 1 row
         else pl->wg = ok256 ? 256 : 512;
-        PLCHK(dmalloc(c, &pl->A, pl->m12 * (size_t)pl->nZ));
-        PLCHK(dmalloc(c, &pl->B, pl->m12));
+        // Slice-loop working set: the transient grids ping-pong between two buffers (A -> [P2] -> B; B -> [P3] -> C;
+        // C -> [P4] -> E; E, PSIH -> [P5] -> F; F -> [P6] -> PSIH, so A, C and F are never live together), and the
+        // lanes share the read-only tables PT / GT: 4 grids per lane + the tables instead of 7.5 per lane, so that two
+        // lanes at 2048^2 (304 MiB) mostly stay inside the 256 MiB Infinity Cache.  Dead (band-limited) rows of C / F
+        // may hold stale data of the other tenant: P4 / P6 never read them.
         PLCHK(dmalloc(c, &pl->C, pl->m12));
+        pl->F = pl->C;
+        if (pl->nZ == 1) pl->A = pl->C;
+        else PLCHK(dmalloc(c, &pl->A, pl->m12 * (size_t)pl->nZ));
+        PLCHK(dmalloc(c, &pl->B, pl->m12));
         PLCHK(dmalloc(c, &pl->E, pl->m12));
-        PLCHK(dmalloc(c, &pl->F, pl->m12));
         PLCHK(dmalloc(c, &pl->PSIH, pl->m12));
-        PLCHK(dmalloc(c, &pl->PT, pl->m12));
-        PLCHK(dmalloc(c, &pl->GT, pl->m12 * (size_t)pl->nZ));
+        if (c->share_PT) { pl->PT = c->share_PT; pl->GT = c->share_GT; pl->tables_shared = true; }
+        else {
+            PLCHK(dmalloc(c, &pl->PT, pl->m12));
+            PLCHK(dmalloc(c, &pl->GT, pl->m12 * (size_t)pl->nZ));
+        }
         PLCHK(dmalloc(c, &pl->bins.rowstart, (size_t)pl->p.m3 * pl->nZ * (size_t)(pl->p.m2 + 1)));
         // dead (band-limited) rows / columns of these grids are never written again: they must read as zero
-        for (float2* q : {pl->C, pl->E, pl->F, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->m12, c->stream));
-        PLHIP(k_build_propagator(pl->PT, pl->kp, 1, c->stream));
-        for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 1, c->stream));
+        for (float2* q : {pl->C, pl->E, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->m12, c->stream));
+        if (!pl->tables_shared) {
+            PLHIP(k_build_propagator(pl->PT, pl->kp, 1, c->stream));
+            for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 1, c->stream));
+        }
     }
     // tilt offset (src/crystalMaker.cu:282-283)
     PLHIP(hipMemcpyAsync(pl->xyzTO_d, pl->xyz0_d, sizeof(float) * n3f, hipMemcpyDeviceToDevice, c->stream));
@@ -661,6 +676,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             PLCHK(fdes_create(&lc, c->device));
             lc->is_lane_ctx = true;
             lc->opt_fft = c->opt_fft; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip;
+            lc->share_PT = pl->PT; lc->share_GT = pl->GT; // read-only tables of the parent plan (built and synchronised above)
             pl->lane_ctx.push_back(lc);
             fdes_plan* lp = nullptr;
             int lrc = fdes_plan_create(lc, p_in, a, &lp);

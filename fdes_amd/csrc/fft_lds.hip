@@ -292,6 +292,33 @@ __device__ __forceinline__ void xform(float2 (&a)[WGeo<WG>::NRV][16], float2* ld
     if constexpr (XF == XF_INV) row_fft<N, WG, true, WAR0, TWR>(a, lds, r, t, tw, gs);
 }
 
+// Row loads, a[h][l] = src[row h][t + T l].  BAND: the columns beyond the 2/3 band limit of a SQUARE grid
+// (|iwc(c)| > N / 3, the largest i with 9 i^2 <= N^2) count as zero and are not fetched.  Columns come in 16
+// blocks of T, so after unrolling each (h, l) is one of three compile-time cases: the block is live (plain load),
+// dead (no load at all) or straddles the limit (two of the 16: a dead lane re-reads element t, a line that is
+// fetched anyway, and is zeroed by a select).  lds_pass() clears the flag when the band limit is not N / 3.
+template <int N, int WG, bool BAND>
+__device__ __forceinline__ void load_rows(float2 (&a)[WGeo<WG>::NRV][16], const float2* __restrict__ src,
+                                          const unsigned (&rbase)[WGeo<WG>::NRV], const int t)
+{
+    constexpr int T = N / 16, LB = N / 3;
+#pragma unroll
+    for (int h = 0; h < WGeo<WG>::NRV; h++)
+#pragma unroll
+        for (int l = 0; l < 16; l++) {
+            const int lo = T * l, hi = T * l + T - 1;
+            const int cls = !BAND ? 0 : ((hi <= LB || lo >= N - LB) ? 0 : ((lo > LB && hi < N - LB) ? 1 : 2));
+            if (cls == 0) a[h][l] = src[rbase[h] + t + T * l];
+            else if (cls == 1) a[h][l] = make_float2(0.f, 0.f);
+            else {
+                const int c = t + T * l;
+                const bool dd = c > LB && c < N - LB;
+                const float2 v = src[rbase[h] + (dd ? t : c)];
+                a[h][l] = dd ? make_float2(0.f, 0.f) : v;
+            }
+        }
+}
+
 template <int N, int WG, int PRE, int MID, int POST, bool STORE_T>
 __global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : 2)) void k_pass(PassArgs A)
 {
@@ -454,17 +481,8 @@ __global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : 2)) void k_pass(Pas
             }
             __syncthreads(); // the staging area becomes the exchange buffer
         } else {
-#pragma unroll
-        for (int h = 0; h < WGeo<WG>::NRV; h++)
-#pragma unroll
-            for (int l = 0; l < 16; l++) {
-                // branch-free: a dead column re-reads this row's element t (a line that is fetched anyway) and is
-                // zeroed by a select, so the 16 loads still issue back to back and no dead line leaves HBM
-                const int c = t + T * l;
-                const bool dd = A.skip_dead_loads && dead_index(iwc(c, N), A.band);
-                const float2 v = in0[rbase[h] + (dd ? t : c)];
-                a[h][l] = dd ? make_float2(0.f, 0.f) : v;
-            }
+        if (A.skip_dead_loads) load_rows<N, WG, true>(a, in0, rbase, t);
+        else load_rows<N, WG, false>(a, in0, rbase, t);
         }
         if constexpr (MID == MID_ZSRC) {
 #pragma unroll
@@ -515,15 +533,22 @@ __global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : 2)) void k_pass(Pas
             // zeroHighFreq tests (float)(i1^2 + i2^2) * 9 / mindim^2 > 1 (src/multisliceSimulation.cu:241).  On the
             // power-of-two grids this kernel serves, mindim^2 < 2^24, so every float on the deciding side of the
             // threshold is exact and the integer comparison is the same predicate, without 32 divisions per thread.
+            // Per row the live columns are |i1| <= Lr, Lr the largest integer with 9 Lr^2 <= mindim^2 - 9 i2^2 (a
+            // wave-uniform value, found once per row); the element test is then one compare against t.
             const int md2 = A.mindim * A.mindim;
 #pragma unroll
             for (int h = 0; h < WGeo<WG>::NRV; h++) {
                 const int i2 = iwc(grow[h], A.nrows);
+                const int q = md2 - 9 * i2 * i2;
+                int Lr = (int)(sqrtf((float)(q > 0 ? q : 0)) * (1.0f / 3.0f));
+                Lr += (9 * (Lr + 1) * (Lr + 1) <= q) ? 1 : 0;
+                Lr -= (9 * Lr * Lr > q) ? 1 : 0; // q < 0: Lr = -1, nothing is live
+                const int tlo = Lr, thi = N - Lr; // live: c <= Lr (c < N/2) or c >= N - Lr (c >= N/2; i1 = N/2 squares like -N/2)
 #pragma unroll
                 for (int l = 0; l < 16; l++) {
-                    const int i1 = iwc(t + T * l, N);
-                    const bool outside = 9 * (i1 * i1 + i2 * i2) > md2;
-                    a[h][l] = outside ? make_float2(0.f, 0.f) : make_float2(a[h][l].x * A.scale, a[h][l].y * A.scale);
+                    const bool live = (l < 8) ? (t <= tlo - T * l) : (t >= thi - T * l);
+                    const float f = live ? A.scale : 0.f;
+                    a[h][l] = make_float2(a[h][l].x * f, a[h][l].y * f);
                 }
             }
         } else if constexpr (MID == MID_SCALE) {
@@ -546,15 +571,8 @@ __global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : 2)) void k_pass(Pas
                 for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], pv[h][l]);
         } else if constexpr (MID == MID_MULPSI) {
             float2 b[WGeo<WG>::NRV][16];
-#pragma unroll
-            for (int h = 0; h < WGeo<WG>::NRV; h++)
-#pragma unroll
-                for (int l = 0; l < 16; l++) {
-                    const int c = t + T * l;
-                    const bool dd = A.skip_dead_loads && dead_index(iwc(c, N), A.band);
-                    const float2 v = in1[rbase[h] + (dd ? t : c)];
-                    b[h][l] = dd ? make_float2(0.f, 0.f) : v;
-                }
+            if (A.skip_dead_loads) load_rows<N, WG, true>(b, in1, rbase, t);
+            else load_rows<N, WG, false>(b, in1, rbase, t);
             xform<N, WG, PRE, true, TWR>(b, lds, r, t, tw, gs);
 #pragma unroll
             for (int h = 0; h < WGeo<WG>::NRV; h++)
@@ -593,7 +611,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : 2)) void k_pass(Pas
                 dead_index(iwc(it * (WGeo<WG>::THR / R) + WGeo<WG>::THR / R - 1, N), A.band) &&
                 (it * (WGeo<WG>::THR / R) > N / 2) == (it * (WGeo<WG>::THR / R) + WGeo<WG>::THR / R - 1 > N / 2))
                 continue;
-            dst[(unsigned)c * ld + (unsigned)rr] = lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))];
+            (dst + (size_t)(it * (WGeo<WG>::THR / R)) * ld)[(unsigned)c0 * ld + (unsigned)rr] = lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))];
         }
     }
 }
@@ -684,7 +702,10 @@ void lds_fft_twiddles(int n, float* tw0, float* tw1)
 hipError_t lds_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs& a_in, hipStream_t st)
 {
     PassArgs a = a_in;
-    if (a.band > 0) a.band_L = live_limit(a.band);
+    if (a.band > 0) {
+        a.band_L = live_limit(a.band);
+        if (a.band_L != n / 3) a.skip_dead_loads = 0; // the kernel's column classes assume the band of a square grid
+    }
     switch (n) {
     case 256: return dispatch_wg<256>(pre, mid, post, st_t, a, st);
     case 512: return dispatch_wg<512>(pre, mid, post, st_t, a, st);
