@@ -33,8 +33,9 @@ def main():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--fft", type=int, default=0, help="engine option fft: 0 auto, 1 rocFFT, 2 hand-written")
     ap.add_argument("--probe-stride", type=int, default=8)
-    ap.add_argument("--lanes", type=int, default=2, help="configurations in flight per GPU (engine option lanes)")
+    ap.add_argument("--lanes", type=int, default=0, help="configurations in flight per GPU (engine option lanes)")
     ap.add_argument("--pass-threads", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=1, help="engine option graph: replay the slice loop as a hipGraph")
     ap.add_argument("--extra-skip-run", type=int, default=1, help="also time the engine default (empty-slice short cut)")
     ap.add_argument("--skip-empty", type=int, default=0,
                     help="1: slices without atoms only get the Fresnel step (engine default); 0 (bench default): every "
@@ -73,6 +74,7 @@ def main():
         """K timed steps on a fresh engine/plan; returns (seconds, plan, engine, loop_ms, loop_slices, fft_ms, fft_n, finite)."""
         eng = fdes_amd.Engine(local, fft=args.fft, probe_stride=0, lanes=args.lanes,
                               pass_threads=args.pass_threads, skip_empty=skip_empty)
+        eng.set_option("graph", args.graph)
         plan = eng.plan(hp, atoms)
 
         def barrier():
@@ -187,7 +189,7 @@ def main():
                                    f"1 frozen-phonon configuration per step per GPU (of 32), mode 0",
                        "wave": [m, m], "slices": m3, "atoms": atoms.n, "configs_per_step": world,
                        "parallelism": f"configs sharded over {world} GPU(s)"},
-            "lanes": plan.lanes(), "skip_empty": args.skip_empty,
+            "lanes": plan.lanes(), "graph": args.graph, "skip_empty": args.skip_empty,
             # bytes the fused loop moves per pixel and slice (P1'/2 + P2/2 + P3 + P4 + P5 + P6 =
             # 4 + 10 + 13.3 + 10.7 + 16 + 16, dead band-limit rows/columns not counted) at the measured rate, and the same
             # rate priced with SURVEY 8d's model of separate FFT passes ((176 + 56 nZ) B/px; may exceed the HBM peak)

@@ -32,7 +32,7 @@ struct fdes_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int opt_fft = 0;   // 0 auto, 1 rocFFT, 2 hand-written
-    int opt_graph = 0;
+    int opt_graph = 1;    // replay the fused slice loop of a configuration as a hipGraph (one instantiated graph per empty-slice pattern)
     uint32_t seed = 1; // src/crystalMaker.cu:292
     bool is_lane_ctx = false;
     int bench_band = 0;   // fdes_bench_pass only
@@ -41,7 +41,7 @@ struct fdes_ctx {
     int band_skip = 1;    // do not move / transform the rows and columns the 2/3 band limit zeroes anyway
     int skip_empty = 1;   // slices without atoms: t = 1, only the Fresnel step is applied (fused loop)
     int lanes_active = 0; // > 0: run_config only deals to the first n lanes (bench: time a kernel without a co-running lane)
-    int lanes = 2;        // configurations in flight at once (own stream + buffers each) in the fused slice loop
+    int lanes = 0;        // configurations in flight at once (own stream + buffers each) in the fused slice loop; 0: by grid size
     int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
     std::map<std::pair<int, int>, Fft2D*> fft_cache; // plans are expensive to create: one per grid size
@@ -88,6 +88,12 @@ struct fdes_plan {
     float2 *A = nullptr, *B = nullptr, *C = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
     float* GT = nullptr;
     bool tables_shared = false; // PT / GT belong to the parent plan (lanes)
+    // hipGraph replay of the fused slice loop (option "graph"): the launch sequence of a configuration depends only on
+    // the number of slices and on which slices are empty, so an instantiated graph is kept per such pattern
+    struct LoopGraph { uint64_t key; hipGraphExec_t exec; int64_t skipped; uint64_t used; };
+    std::vector<LoopGraph> graphs;
+    uint64_t graph_tick = 0;
+    bool capturing = false;
     std::vector<EvPair> probe;
     size_t probe_used = 0;
     uint64_t fft_calls = 0;
@@ -310,7 +316,7 @@ int fused_slice(fdes_plan* pl, int s)
     a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
     // roofline probe: P5 is the longest kernel of the loop; every probe_stride-th launch is bracketed by events
     const int pstride = pl->parent_ctx ? pl->parent_ctx->probe_stride : c->probe_stride;
-    const bool probe = pstride > 0 && (pl->fft_calls++ % (uint64_t)pstride) == 0;
+    const bool probe = !pl->capturing && pstride > 0 && (pl->fft_calls++ % (uint64_t)pstride) == 0;
     EvPair* ev = nullptr;
     if (probe) {
         if (pl->probe_used == pl->probe.size()) {
@@ -380,9 +386,57 @@ int slice_loop(fdes_plan* pl, int nslices)
 {
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
     if (pl->fused) {
-        RC(fused_enter(pl));
-        for (int s = 0; s < nslices; s++) RC(fused_slice(pl, s));
-        return fused_leave(pl, nslices > 0);
+        fdes_ctx* c = pl->ctx;
+        const fdes_ctx* oc = pl->parent_ctx ? pl->parent_ctx : c; // lanes follow the owner's runtime options
+        const bool timing_probe = (oc->probe_stride > 0);
+        if (!oc->opt_graph || timing_probe || nslices < 1) {
+            RC(fused_enter(pl));
+            for (int s = 0; s < nslices; s++) RC(fused_slice(pl, s));
+            return fused_leave(pl, nslices > 0);
+        }
+        // key: slice count, band option and the empty-slice pattern (FNV-1a over one bit per slice)
+        uint64_t key = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+        mix((uint64_t)nslices);
+        mix((uint64_t)c->band_skip);
+        if (!pl->seg_h.empty())
+            for (int q = 0; q < pl->p.m3; q++) mix(pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ] ? 2u : 3u);
+        fdes_plan::LoopGraph* g = nullptr;
+        for (auto& e : pl->graphs) if (e.key == key) g = &e;
+        if (!g) {
+            const int64_t skipped0 = pl->slices_skipped;
+            pl->capturing = true;
+            hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
+            int rc = FDES_OK;
+            if (e == hipSuccess) {
+                rc = fused_enter(pl);
+                for (int s = 0; s < nslices && rc == FDES_OK; s++) rc = fused_slice(pl, s);
+                if (rc == FDES_OK) rc = fused_leave(pl, true);
+            }
+            hipGraph_t graph = nullptr;
+            hipError_t e2 = (e == hipSuccess) ? hipStreamEndCapture(c->stream, &graph) : e;
+            pl->capturing = false;
+            const int64_t skipped = pl->slices_skipped - skipped0;
+            pl->slices_skipped = skipped0;
+            if (rc != FDES_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            HIPCHK(c, e2);
+            hipGraphExec_t exec = nullptr;
+            hipError_t e3 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            HIPCHK(c, e3);
+            if (pl->graphs.size() >= 8) { // drop the least recently used pattern
+                size_t lru = 0;
+                for (size_t i = 1; i < pl->graphs.size(); i++) if (pl->graphs[i].used < pl->graphs[lru].used) lru = i;
+                (void)hipGraphExecDestroy(pl->graphs[lru].exec);
+                pl->graphs.erase(pl->graphs.begin() + (long)lru);
+            }
+            pl->graphs.push_back({key, exec, skipped, 0});
+            g = &pl->graphs.back();
+        }
+        g->used = ++pl->graph_tick;
+        HIPCHK(c, hipGraphLaunch(g->exec, c->stream));
+        pl->slices_skipped += g->skipped;
+        return FDES_OK;
     }
     for (int s = 0; s < nslices; s++) {
         RC(phase_grating(pl, pl->xyzFP_d, g, s));
@@ -505,7 +559,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "bench_band")) { c->bench_band = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "skip_empty")) { c->skip_empty = value != 0; return FDES_OK; }
-    if (!std::strcmp(key, "lanes")) { if (value < 1 || value > 4) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "lanes")) { if (value < 0 || value > 4) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "probe_stride")) { c->probe_stride = (int)value; return FDES_OK; }
     return FDES_EINVAL;
 }
@@ -525,6 +579,7 @@ int fdes_plan_destroy(fdes_plan* pl)
                     pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A == pl->C ? nullptr : pl->A, pl->B, pl->C, pl->E, pl->PSIH,
                     pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT}; // F aliases C
     for (void* q : ptrs) if (q) (void)hipFree(q);
+    for (auto& g : pl->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto& e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : pl->probe) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     fdes_params_release(&pl->p0);
@@ -670,12 +725,15 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLHIP(hipMemcpyAsync(pl->xyzTO_d, pl->xyz0_d, sizeof(float) * n3f, hipMemcpyDeviceToDevice, c->stream));
     PLCHK(tilt_coordinates(pl, pl->xyzTO_d, pl->p.tilt_offset_x, pl->p.tilt_offset_y, pl->p.tilt_offset_z));
     PLHIP(hipStreamSynchronize(c->stream));
-    if (pl->fused && c->lanes > 1 && !c->is_lane_ctx) {
-        for (int l = 1; l < c->lanes; l++) {
+    // lanes hide the gap between dependent kernels of one stream (about 8 us on this part): two at 2048^2 and above
+    // (20 us kernels; a third lane only thrashes the Infinity Cache), three where the kernels are as short as the gap
+    const int nlanes = c->lanes > 0 ? c->lanes : (pl->m12 <= (size_t)1024 * 1024 ? 3 : 2);
+    if (pl->fused && nlanes > 1 && !c->is_lane_ctx) {
+        for (int l = 1; l < nlanes; l++) {
             fdes_ctx* lc = nullptr;
             PLCHK(fdes_create(&lc, c->device));
             lc->is_lane_ctx = true;
-            lc->opt_fft = c->opt_fft; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip;
+            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip;
             lc->share_PT = pl->PT; lc->share_GT = pl->GT; // read-only tables of the parent plan (built and synchronised above)
             pl->lane_ctx.push_back(lc);
             fdes_plan* lp = nullptr;
