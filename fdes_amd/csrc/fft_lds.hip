@@ -297,22 +297,30 @@ __device__ __forceinline__ void xform(float2 (&a)[WGeo<WG>::NRV][16], float2* ld
 // blocks of T, so after unrolling each (h, l) is one of three compile-time cases: the block is live (plain load),
 // dead (no load at all) or straddles the limit (two of the 16: a dead lane re-reads element t, a line that is
 // fetched anyway, and is zeroed by a select).  lds_pass() clears the flag when the band limit is not N / 3.
-template <int N, int WG, bool BAND>
+#ifndef FDES_P5_PREFETCH
+#define FDES_P5_PREFETCH 0 // requesting the second operand with the first: measured, no gain (A/B 12.1k vs 12.1k), 14 more VGPRs
+#endif
+template <int N, int WG>
 __device__ __forceinline__ void load_rows(float2 (&a)[WGeo<WG>::NRV][16], const float2* __restrict__ src,
-                                          const unsigned (&rbase)[WGeo<WG>::NRV], const int t)
+                                          const unsigned (&rbase)[WGeo<WG>::NRV], const int t, const bool band)
 {
     constexpr int T = N / 16, LB = N / 3;
+    // `band` is uniform.  The straddling blocks are common code for both settings (the flag only feeds the select),
+    // the dead blocks are loads under a uniform branch: written as two whole variants under one `if`, the compiler
+    // waited for the straddling loads inside the branch, one HBM round trip before the other 28 loads were issued.
 #pragma unroll
     for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
         for (int l = 0; l < 16; l++) {
             const int lo = T * l, hi = T * l + T - 1;
-            const int cls = !BAND ? 0 : ((hi <= LB || lo >= N - LB) ? 0 : ((lo > LB && hi < N - LB) ? 1 : 2));
+            const int cls = (hi <= LB || lo >= N - LB) ? 0 : ((lo > LB && hi < N - LB) ? 1 : 2);
             if (cls == 0) a[h][l] = src[rbase[h] + t + T * l];
-            else if (cls == 1) a[h][l] = make_float2(0.f, 0.f);
-            else {
+            else if (cls == 1) {
+                a[h][l] = make_float2(0.f, 0.f);
+                if (!band) a[h][l] = src[rbase[h] + t + T * l];
+            } else {
                 const int c = t + T * l;
-                const bool dd = c > LB && c < N - LB;
+                const bool dd = band && c > LB && c < N - LB;
                 const float2 v = src[rbase[h] + (dd ? t : c)];
                 a[h][l] = dd ? make_float2(0.f, 0.f) : v;
             }
@@ -481,8 +489,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : 2)) void k_pass(Pas
             }
             __syncthreads(); // the staging area becomes the exchange buffer
         } else {
-        if (A.skip_dead_loads) load_rows<N, WG, true>(a, in0, rbase, t);
-        else load_rows<N, WG, false>(a, in0, rbase, t);
+        load_rows<N, WG>(a, in0, rbase, t, A.skip_dead_loads != 0);
         }
         if constexpr (MID == MID_ZSRC) {
 #pragma unroll
@@ -506,6 +513,9 @@ __global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : 2)) void k_pass(Pas
 #pragma unroll
                 for (int l = 0; l < 16; l++) gvv[h][l] = gtab[rbase[h] + t + T * l];
         }
+        // second operand of the product: requested with the first so that its HBM round trip overlaps the first transform
+        float2 b[(MID == MID_MULPSI) ? WGeo<WG>::NRV : 1][16];
+        if constexpr (MID == MID_MULPSI && FDES_P5_PREFETCH) load_rows<N, WG>(b, in1, rbase, t, A.skip_dead_loads != 0);
         xform<N, WG, PRE, false, TWR>(a, lds, r, t, tw, gs);
         if constexpr (MID == MID_EXPIV) {
 #pragma unroll
@@ -570,9 +580,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : 2)) void k_pass(Pas
 #pragma unroll
                 for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], pv[h][l]);
         } else if constexpr (MID == MID_MULPSI) {
-            float2 b[WGeo<WG>::NRV][16];
-            if (A.skip_dead_loads) load_rows<N, WG, true>(b, in1, rbase, t);
-            else load_rows<N, WG, false>(b, in1, rbase, t);
+            if constexpr (!FDES_P5_PREFETCH) load_rows<N, WG>(b, in1, rbase, t, A.skip_dead_loads != 0);
             xform<N, WG, PRE, true, TWR>(b, lds, r, t, tw, gs);
 #pragma unroll
             for (int h = 0; h < WGeo<WG>::NRV; h++)

@@ -6,6 +6,6 @@ for cfg in "$@"; do
   python - "$1" "$2" <<'PY'
 import json,sys
 d=json.load(open('/tmp/bv.json'))
-print("lanes",sys.argv[1],"wg",sys.argv[2],"value",d["value"],"ms/step",d["ms_per_step"],"P6 us",d["roofline"]["launch_us"])
+print("lanes",sys.argv[1],"wg",sys.argv[2],"value",d["value"],"ms/step",d["ms_per_step"],"P5 us",d["roofline"]["launch_us"])
 PY
 done
