@@ -297,6 +297,11 @@ __device__ __forceinline__ void xform(float2 (&a)[WGeo<WG>::NRV][16], float2* ld
 // blocks of T, so after unrolling each (h, l) is one of three compile-time cases: the block is live (plain load),
 // dead (no load at all) or straddles the limit (two of the 16: a dead lane re-reads element t, a line that is
 // fetched anyway, and is zeroed by a select).  lds_pass() clears the flag when the band limit is not N / 3.
+#ifndef FDES_WAVES
+#define FDES_WAVES 2 // waves per SIMD the 256/512-thread geometries are compiled for
+#endif
+// two-operand passes need the registers of two waves per SIMD
+constexpr int pass_waves(int mid) { return (mid == MID_MULPSI || mid == MID_GTABN) ? 2 : FDES_WAVES; }
 #ifndef FDES_P5_PREFETCH
 #define FDES_P5_PREFETCH 0 // requesting the second operand with the first: measured, no gain (A/B 12.1k vs 12.1k), 14 more VGPRs
 #endif
@@ -328,12 +333,12 @@ __device__ __forceinline__ void load_rows(float2 (&a)[WGeo<WG>::NRV][16], const 
 }
 
 template <int N, int WG, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : 2)) void k_pass(PassArgs A)
+__global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : pass_waves(MID))) void k_pass(PassArgs A)
 {
     using G_ = Geo<N, WG>;
     constexpr int T = G_::T, R = G_::R, RH = G_::RH;
     extern __shared__ float2 lds[];
-    constexpr bool TWR = (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && MID != MID_PTAB && MID != MID_GTABN);
+    constexpr bool TWR = (pass_waves(MID) == 2) && (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && MID != MID_PTAB && MID != MID_GTABN);
     Tw tw;
     tw.g0 = reinterpret_cast<const float2*>(A.tw0);
     tw.g1 = reinterpret_cast<const float2*>(A.tw1);
