@@ -426,13 +426,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : pass_waves(MID))) v
     } else {
         if constexpr (MID == MID_ATOMS) {
             // squareAtoms_d (src/crystalMaker.cu:73-123) without a deposit grid: the few atoms whose bilinear
-            // footprint touches this row group are read from the (slice, species, row)-sorted records and added
-            // straight into the registers of the threads that own the four pixels.  Every thread walks the same
-            // atoms (uniform control flow); contributions are added in sorted order (deterministic).
-#pragma unroll
-            for (int h = 0; h < WGeo<WG>::NRV; h++)
-#pragma unroll
-                for (int l = 0; l < 16; l++) a[h][l] = make_float2(0.f, 0.f);
+            // footprint touches this row group are read from the (slice, species, row)-sorted records.
             const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs);
             // candidate ranges of both components (4 independent loads), then the records are staged through LDS
             // (free before the first exchange) so that the walk below is not a chain of dependent global loads
@@ -459,37 +453,48 @@ __global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : pass_waves(MID))) v
                 }
                 return;
             }
-            AtomRec* sh = reinterpret_cast<AtomRec*>(lds);
-            constexpr int CAP = 2048;
-#pragma unroll 1
-            for (int comp = 0; comp < 2; comp++) {
-#pragma unroll 1
-                for (int base = plo[comp]; base < phi[comp]; base += CAP) {
-                    const int nb = (phi[comp] - base < CAP) ? phi[comp] - base : CAP;
-                    __syncthreads();
-                    for (int i = tid; i < nb; i += WGeo<WG>::THR) sh[i] = recs[base + i];
-                    __syncthreads();
-#pragma unroll 1
-                    for (int p = 0; p < nb; p++) {
-                        const AtomRec ar = sh[p];
-                        const float a1 = fabsf(ar.r1), a2 = fabsf(ar.r2);
-                        const int s1 = ar.r1 < 0.f ? -1 : 1, s2 = ar.r2 < 0.f ? -1 : 1;
+            // The row tile is zeroed in LDS, ONE wave adds the bilinear weights with LDS float atomics (lane = atom,
+            // 64 at a time, in the sorted order of the records), and every thread then picks up its own 32 pixels.
+            // One wave only: instructions of a wave reach the LDS in program order and colliding lanes of one
+            // instruction are serialised by the hardware in a fixed order, so the sums do not depend on timing.
+            {
+                const int rd0 = t + (t >> 4);
 #pragma unroll
-                        for (int px = 0; px < 4; px++) {
-                            // pixel order of the reference: (i1,i2), (i1,i2+s2), (i1+s1,i2+s2), (i1+s1,i2)
-                            const int c = ar.i1 + ((px == 2 || px == 3) ? s1 : 0);
-                            const int rr = ar.i2 + ((px == 1 || px == 2) ? s2 : 0) - row0;
-                            const float w = ((px == 2 || px == 3) ? a1 : (1 - a1)) * ((px == 1 || px == 2) ? a2 : (1 - a2)) * ar.occ;
-                            if (rr < 0 || rr >= R) continue;
-                            if ((rr % RH) != r || (c % T) != t) continue;
-                            const int hh = rr / RH, ll = c / T;
+                for (int h = 0; h < WGeo<WG>::NRV; h++) {
+                    float2* row = lds + (r + h * RH) * G_::LDROW;
 #pragma unroll
-                            for (int h = 0; h < WGeo<WG>::NRV; h++)
+                    for (int l = 0; l < 16; l++) row[rd0 + (T + T / 16) * l] = make_float2(0.f, 0.f);
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    float* ldsf = reinterpret_cast<float*>(lds);
+#pragma unroll 1
+                    for (int comp = 0; comp < 2; comp++) {
+#pragma unroll 1
+                        for (int base = plo[comp]; base < phi[comp]; base += 64) {
+                            const int i = base + tid;
+                            if (i < phi[comp]) {
+                                const AtomRec ar = recs[i];
+                                const float a1 = fabsf(ar.r1), a2 = fabsf(ar.r2);
+                                const int s1 = ar.r1 < 0.f ? -1 : 1, s2 = ar.r2 < 0.f ? -1 : 1;
 #pragma unroll
-                                for (int l = 0; l < 16; l++)
-                                    if (h == hh && l == ll) { if (comp) a[h][l].y += w; else a[h][l].x += w; }
+                                for (int px = 0; px < 4; px++) {
+                                    // pixel order of the reference: (i1,i2), (i1,i2+s2), (i1+s1,i2+s2), (i1+s1,i2)
+                                    const int c = ar.i1 + ((px == 2 || px == 3) ? s1 : 0);
+                                    const int rr = ar.i2 + ((px == 1 || px == 2) ? s2 : 0) - row0;
+                                    const float w = ((px == 2 || px == 3) ? a1 : (1 - a1)) * ((px == 1 || px == 2) ? a2 : (1 - a2)) * ar.occ;
+                                    if (rr >= 0 && rr < R && c >= 0 && c < N) atomicAdd(&ldsf[2 * (rr * G_::LDROW + c + (c >> 4)) + comp], w);
+                                }
+                            }
                         }
                     }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < WGeo<WG>::NRV; h++) {
+                    const float2* row = lds + (r + h * RH) * G_::LDROW;
+#pragma unroll
+                    for (int l = 0; l < 16; l++) a[h][l] = row[rd0 + (T + T / 16) * l];
                 }
             }
             __syncthreads(); // the staging area becomes the exchange buffer
