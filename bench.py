@@ -164,8 +164,8 @@ def main():
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
                 "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": int(fft_n),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "timed": "HIP events around every %d-th launch during one configuration run on lane 0 right after the "
-                         "timed steps (other lanes idle)" % args.probe_stride}
+                "timed": "HIP start/stop events of the dispatch itself (hipExtLaunchKernelGGL) on every %d-th launch during one "
+                         "configuration run on lane 0 right after the timed steps (other lanes idle)" % args.probe_stride}
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline:
         cpu = cpu_baseline(hp, atoms, m)

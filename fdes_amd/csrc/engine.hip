@@ -326,10 +326,10 @@ int fused_slice(fdes_plan* pl, int s)
             pl->probe.push_back(e);
         }
         ev = &pl->probe[pl->probe_used++];
-        HIPCHK(c, hipEventRecord(ev->a, c->stream));
+        a5.ev_start = ev->a; // timestamps of the dispatch itself (hipExtLaunchKernelGGL)
+        a5.ev_stop = ev->b;
     }
     HIPCHK(c, lds_pass(m1, XF_INV, MID_MULPSI, XF_FWD, true, a5, c->stream));
-    if (ev) HIPCHK(c, hipEventRecord(ev->b, c->stream));
     PassArgs a6 = pass_y(pl);
     a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->PSIH;
     a6.band = band; a6.live_rows_only = bs;

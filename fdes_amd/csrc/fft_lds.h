@@ -8,6 +8,7 @@
 #ifndef FDES_FFT_LDS_H_
 #define FDES_FFT_LDS_H_
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 namespace fdes {
 
@@ -53,6 +54,11 @@ struct PassArgs {
     const void* recs = nullptr;  // AtomRec[] sorted by (slice, species, row)
     const int* rowstart = nullptr; // [q][nrows + 1]
     int q0 = -1, q1 = -1;        // (slice * nZ + species) deposited into the real / imaginary component (-1: none)
+    // host side only: when set, the dispatch is bracketed by these two events through hipExtLaunchKernelGGL, whose
+    // timestamps come from the dispatch packet itself (kernel begin / end, what a profiler reports) rather than from
+    // marker packets before and after it
+    void* ev_start = nullptr;
+    void* ev_stop = nullptr;
 };
 
 // Row lengths the kernels are instantiated for.

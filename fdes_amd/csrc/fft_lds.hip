@@ -657,6 +657,12 @@ template <int N, int WG, int PRE, int MID, int POST, bool ST> hipError_t launch(
         if (g_hi > g_lo) groups = g_lo + (a.nrows / G_::R - g_hi); // else: everything is live
         else { PassArgs b = a; b.live_rows_only = 0; hipLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, b); return hipGetLastError(); }
     }
+    if (a.ev_start && a.ev_stop) {
+        PassArgs b = a;
+        b.ev_start = b.ev_stop = nullptr;
+        hipExtLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, b);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, a);
     return hipGetLastError();
 }
