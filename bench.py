@@ -85,6 +85,10 @@ def main():
             torch.cuda.synchronize()
 
         plan.begin_measurement(0)
+        # plan preparation (not a step): one configuration per lane so that every lane has captured and instantiated its
+        # slice-loop graph whatever W is
+        for lane in range(plan.lanes()):
+            plan.run_config(0, 3000 + lane, 0.0)
         for w in range(args.warmup):
             plan.run_config(0, 1000 + rank + world * w, 0.0)  # untimed, weight 0: does not touch the sum
         plan.sync()

@@ -81,6 +81,27 @@ def case_c1():
     return hp, HostAtoms(Z, xyz, dwf, 1.0)
 
 
+def si001(ncx, ncy, ncz, a=5.431e-10, b=0.4668e-20):
+    """Si diamond cells viewed along [001] (the reference's ExampleSpecimens/Si_001_11k_cnf is 19 x 19 x 4 cells =
+    11 552 atoms), centred per axis."""
+    fcc = [(0, 0, 0), (0, .5, .5), (.5, 0, .5), (.5, .5, 0)]
+    base = fcc + [(x + .25, y + .25, z + .25) for (x, y, z) in fcc]
+    cells = np.array([(cx, cy, cz) for cx in range(ncx) for cy in range(ncy) for cz in range(ncz)], np.float64)
+    xyz = (cells[:, None, :] + np.array(base)[None, :, :]).reshape(-1, 3) * a
+    xyz -= (xyz.max(axis=0) + xyz.min(axis=0)) / 2
+    return np.full(len(xyz), 14, np.int32), xyz.astype(np.float32), np.full(len(xyz), b, np.float32)
+
+
+def case_c2(n=512, dn=256, m3=64, cells=(19, 19, 4)):
+    """C2: Si[001] 11 552 atoms, 1024^2 wave, 64 slices, 1 configuration (no frozen phonons), imaging mode."""
+    Z, xyz, dwf = si001(*cells)
+    d = cells[0] * 5.431e-10 / n
+    d3 = cells[2] * 5.431e-10 / m3
+    hp = make_params(1, E0=200e3, n1=n, n2=n, dn1=dn, dn2=dn, d1=d, d2=d, m3=m3, d3=d3, subSlTh=d3, mode=0, frPh=0,
+                     pD=0.0, imPot=0.05, ObjAp=15e-3, C1_0=-40e-9, C3_0=1e-3)
+    return hp, HostAtoms(Z, xyz, dwf, 1.0)
+
+
 def case_c3(k=30, n=1024, dn=512, m3=256, frPh=32):
     """C3 (headline): Au cuboctahedron, 2048^2 wave, 256 slices, 32 frozen-phonon configs."""
     xyz = au_cuboctahedron(k)

@@ -294,3 +294,63 @@ def test_srtio3_qsc_through_the_cli(oracle, tmp_path):
     print("[parity] SrTiO3 .qsc CLI vs f64 oracle: max rel err", err, "contrast", ref.std() / ref.mean())
     assert ref.std() / ref.mean() > 1e-3      # a non-trivial image
     assert err < 2e-4
+
+
+def test_c2_si001_1024(engine, oracle):
+    """BASELINE config 2 at full size: Si[001] 19x19x4 cells = 11 552 atoms, 1024^2 wave, 64 slices, one
+    configuration; image against the float64 oracle (float32 oracle beside it)."""
+    hp, at = S.case_c2()
+    assert at.n == 11552
+    fdes_amd.consistent(hp)
+    out = engine.build_measurements(hp, at)["image"]
+    r64 = oracle.build_measurements(hp, at, prec="f64")["image"]
+    r32 = oracle.build_measurements(hp, at, prec="f32")["image"]
+    assert r64.std() / r64.mean() > 1e-2
+    check(out, r64, r32, 2e-5, "C2 Si[001] 1024^2 x 64 slices image")
+
+
+def test_c4_beam_tilt_series_reduced(engine, oracle):
+    """BASELINE config 4 with the series cut to 2 x 2 beam tilts x 2 frozen-phonon configurations and half the
+    thickness (SrTiO3 9x9x10 cells, 1024^2 wave, 20 slices): beam tilt + Tukey window + band limit on the way in,
+    phonon averaging per tilt, three lanes + graph replay on the way through."""
+    hp, at = S.case_c4(n3=4, frPh=2, cells=(9, 9, 10))
+    fdes_amd.consistent(hp)
+    assert hp.c.doBeamTilt == 1 and (hp.c.m1, hp.c.m3, at.n) == (1024, 20, 4050)
+    out = engine.build_measurements(hp, at)["image"]
+    r32 = oracle.build_measurements(hp, at, prec="f32")["image"]
+    for k in range(4):
+        e = relerr(out[k], r32[k])
+        print(f"[parity] C4 tilt {k}: E(gpu vs cpu_f32) = {e:.3e}")
+        assert e < 5e-5
+    assert relerr(out[0], out[3]) > 1e-3      # different tilts give different images
+
+
+def test_c5_size_propagation_properties(engine):
+    """BASELINE config 5 grid (4096^2): linearity and free-space norm conservation of the propagation unit."""
+    import torch
+    hp, at = S.case_c5(k=2, frPh=0)
+    hp.set(m3=2)
+    fdes_amd.consistent(hp)
+    pl = engine.plan(hp, at)
+    m = 4096
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.randn(m, m, 2, device="cuda", generator=gen)
+    b = torch.randn(m, m, 2, device="cuda", generator=gen)
+    t = torch.zeros(m, m, 2, device="cuda")
+    t[..., 0] = 1.0
+    torch.cuda.synchronize()
+
+    def prop(x, n=1):
+        y = x.clone()
+        torch.cuda.synchronize()
+        for _ in range(n):
+            pl.propagate_dev(y.data_ptr(), t.data_ptr())
+        pl.sync()
+        return y
+
+    pa, pb, pab = prop(a), prop(b), prop(2.0 * a - 0.5 * b)
+    lin = float((pab - (2.0 * pa - 0.5 * pb)).norm() / pab.norm())
+    drift = abs(float(prop(pa, 3).norm() / pa.norm()) - 1.0)
+    print("[parity] 4096^2 linearity residual:", lin, "norm drift over 3 free-space steps:", drift)
+    assert lin < 5e-6 and drift < 1e-5
+    pl.close()
