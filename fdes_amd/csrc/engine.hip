@@ -554,7 +554,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "fft")) { if (value < 0 || value > 2) return FDES_EINVAL; c->opt_fft = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
-    if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_band")) { c->bench_band = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
@@ -693,8 +693,10 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
                            lds_fft_rows_per_block(m1, 256) >= 4 && lds_fft_rows_per_block(m2, 256) >= 4; // >= 32-byte transposed segments
         // 256-thread workgroups (two per CU) measured faster or equal for every pass up to 2048-point rows, with one
         // or two lanes; 4096-point rows keep 512 threads (256 would cut the transposed-store segments to 16 bytes)
+        // up to 1024^2 a pass is as long as its slowest workgroup: one row per thread, four rows per workgroup
+        const bool small = m1 <= 1024 && m2 <= 1024;
         if (c->pass_threads == 512) pl->wg = 512;
-        else if (c->pass_threads == 513 && ok256 && m1 >= 512 && m2 >= 512 && m1 <= 2048 && m2 <= 2048) pl->wg = 513; // 512 threads x 1 row
+        else if ((c->pass_threads == 1 || c->pass_threads == 513 || (c->pass_threads == 0 && small)) && m1 <= 2048 && m2 <= 2048) pl->wg = 1;
         else pl->wg = ok256 ? 256 : 512;
         // Slice-loop working set: the transient grids ping-pong between two buffers (A -> [P2] -> B; B -> [P3] -> C;
         // C -> [P4] -> E; E, PSIH -> [P5] -> F; F -> [P6] -> PSIH, so A, C and F are never live together), and the
@@ -1063,7 +1065,7 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
         PassArgs A;
         A.in0 = a; A.in1 = b; A.out = o; A.zsrc = a; A.gtab = g; A.ptab = pt; A.tw0 = f.tw0x; A.tw1 = f.tw1x; A.nrows = n;
         A.nspecies = 1; A.species_stride = m12; A.scale = 1.f; A.mindim = n;
-        A.wg = c->pass_threads == 256 ? 256 : (c->pass_threads == 513 ? 513 : 512);
+        A.wg = c->pass_threads == 256 ? 256 : ((c->pass_threads == 513 || c->pass_threads == 1) && n <= 2048 ? 1 : 512);
         if (c->bench_band) { // micro-benchmark of the band-limit bookkeeping: bit 0 live rows only, bit 1 dead loads, bit 2 dead stores
             A.band = n * n;
             A.live_rows_only = (c->bench_band & 1) ? 1 : 0;

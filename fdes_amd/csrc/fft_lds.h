@@ -42,7 +42,7 @@ struct PassArgs {
     size_t species_stride = 0;   // elements between species grids (in0 and gtab)
     float scale = 1.f;
     int mindim = 0;              // min(m1, m2) for the band limit
-    int wg = 512;                // threads per workgroup (512 or 256)
+    int wg = 512;                // workgroup geometry: 512 or 256 threads x 2 rows per thread, 1 = n/4 threads x 1 row (4 rows per workgroup)
     // Band limit bookkeeping (band = mindim^2 > 0 enables it): frequency index i is dead iff 9 i^2 > band, i.e. outside
     // the radial 2/3 mask whatever the other index is.  Dead rows/columns hold exact zeros that nobody needs to move.
     int band = 0;

@@ -154,11 +154,13 @@ inline int live_limit(int band)
     return L;
 }
 
-// Workgroup geometries (template parameter WG): 256 -> 256 threads x 2 rows per thread, 512 -> 512 threads x 2 rows,
-// 513 -> 512 threads x 1 row per thread (same 4 rows / 68 KiB as 256 at 2048 points, twice the waves per SIMD).
+// Workgroup geometries (template parameter WG): even -> WG threads x 2 rows per thread (256: default up to 2048
+// points, 512: 4096 points); odd -> (WG - 1) threads x 1 row per thread, instantiated as N / 4 + 1 only, i.e. four
+// rows per workgroup (the shortest dependency chain per workgroup and the most workgroups: grids of 1024^2 and below
+// are bound by the latency of one workgroup, not by throughput; at 2048^2 it is 10 % slower than 256 x 2).
 template <int WG> struct WGeo {
-    static constexpr int THR = (WG == 513) ? 512 : WG;
-    static constexpr int NRV = (WG == 513) ? 1 : 2;
+    static constexpr int THR = (WG & 1) ? WG - 1 : WG;
+    static constexpr int NRV = (WG & 1) ? 1 : 2;
 };
 
 // WG threads per workgroup (512: one workgroup per CU; 256: two per CU, 2 waves per SIMD either way ->
@@ -333,7 +335,7 @@ __device__ __forceinline__ void load_rows(float2 (&a)[WGeo<WG>::NRV][16], const 
 }
 
 template <int N, int WG, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(WGeo<WG>::THR, (WG == 513 ? 4 : pass_waves(MID))) void k_pass(PassArgs A)
+__global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) void k_pass(PassArgs A)
 {
     using G_ = Geo<N, WG>;
     constexpr int T = G_::T, R = G_::R, RH = G_::RH;
@@ -695,14 +697,14 @@ template <int N, int WG> hipError_t dispatch(int pre, int mid, int post, bool st
 template <int N> hipError_t dispatch_wg(int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
 {
     if (a.wg == 256) return dispatch<N, 256>(pre, mid, post, st_t, a, st);
-    if constexpr (N >= 512 && N <= 2048) { if (a.wg == 513) return dispatch<N, 513>(pre, mid, post, st_t, a, st); }
+    if constexpr (N <= 2048) { if (a.wg == 1) return dispatch<N, N / 4 + 1>(pre, mid, post, st_t, a, st); }
     return dispatch<N, 512>(pre, mid, post, st_t, a, st);
 }
 
 } // namespace
 
 bool lds_fft_supported_len(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
-int lds_fft_rows_per_block(int n, int wg) { return (wg == 256 ? 256 * 2 : (wg == 513 ? 512 * 1 : 512 * 2)) * 16 / n; }
+int lds_fft_rows_per_block(int n, int wg) { return wg == 1 ? 4 : (wg == 256 ? 256 * 2 : 512 * 2) * 16 / n; }
 
 void lds_fft_twiddles(int n, float* tw0, float* tw1)
 {
