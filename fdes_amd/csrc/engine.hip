@@ -727,9 +727,11 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLHIP(hipMemcpyAsync(pl->xyzTO_d, pl->xyz0_d, sizeof(float) * n3f, hipMemcpyDeviceToDevice, c->stream));
     PLCHK(tilt_coordinates(pl, pl->xyzTO_d, pl->p.tilt_offset_x, pl->p.tilt_offset_y, pl->p.tilt_offset_z));
     PLHIP(hipStreamSynchronize(c->stream));
-    // lanes hide the gap between dependent kernels of one stream (about 8 us on this part): two at 2048^2 and above
-    // (20 us kernels; a third lane only thrashes the Infinity Cache), three where the kernels are as short as the gap
-    const int nlanes = c->lanes > 0 ? c->lanes : (pl->m12 <= (size_t)1024 * 1024 ? 3 : 2);
+    // lanes hide the gap between dependent kernels of one stream (about 8 us on this part).  Two by default: a third
+    // lane helps one-species 1024^2 runs (+12 %) but costs three-species ones 19 % (HIP maps streams onto a few
+    // hardware queues; which lanes end up sharing one is not under our control), and only thrashes the Infinity Cache
+    // at 2048^2.
+    const int nlanes = c->lanes > 0 ? c->lanes : 2;
     if (pl->fused && nlanes > 1 && !c->is_lane_ctx) {
         for (int l = 1; l < nlanes; l++) {
             fdes_ctx* lc = nullptr;

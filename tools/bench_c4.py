@@ -4,11 +4,11 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fdes_amd
 from tests import specimens as S
-n3, frph = 4, 8
+n3, frph = 4, int(os.environ.get("FRPH", "8"))
 hp, at = S.case_c4(n3=n3, frPh=frph)
 fdes_amd.consistent(hp)
 for lanes in ([int(a) for a in sys.argv[1:]] or [2, 3]):
-    eng = fdes_amd.Engine(0, lanes=lanes)
+    eng = fdes_amd.Engine(0, lanes=lanes, skip_empty=int(os.environ.get('SKIP', '1')))
     pl = eng.plan(hp, at)
     pl.begin_measurement(0)
     for j in range(3):
