@@ -261,12 +261,13 @@ int fused_potential_pair(fdes_plan* pl, int s0)
 {
     fdes_ctx* c = pl->ctx;
     const int m1 = pl->p.m1, m2 = pl->p.m2;
-    for (int z = 0; z < pl->nZ; z++) {
+    {   // one launch, grid.y = species
         PassArgs a = pass_x(pl);
-        a.out = pl->A + (size_t)z * pl->m12;
+        a.out = pl->A;
+        a.nspecies = pl->nZ; a.species_stride = pl->m12;
         a.recs = pl->bins.recs_sorted; a.rowstart = pl->bins.rowstart;
-        a.q0 = s0 * pl->nZ + z;
-        a.q1 = (s0 + 1 < pl->p.m3) ? (s0 + 1) * pl->nZ + z : -1;
+        a.q0 = s0 * pl->nZ;
+        a.q1 = (s0 + 1 < pl->p.m3) ? (s0 + 1) * pl->nZ : -1;
         HIPCHK(c, lds_pass(m1, XF_FWD, MID_ATOMS, XF_NONE, true, a, c->stream));
     }
     PassArgs b = pass_y(pl);

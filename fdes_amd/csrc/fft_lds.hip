@@ -395,6 +395,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
     const float2* __restrict__ ptab = A.ptab ? reinterpret_cast<const float2*>(A.ptab) + gbase : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
     float2* __restrict__ zsrc = A.zsrc ? reinterpret_cast<float2*>(A.zsrc) + gbase : nullptr;
+    if constexpr (MID == MID_ATOMS) A.out += (size_t)blockIdx.y * A.species_stride; // one launch covers every species
     float2* __restrict__ outn = reinterpret_cast<float2*>(A.out) + gbase;
 
     float2 a[WGeo<WG>::NRV][16];
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
             int plo[2] = {0, 0}, phi[2] = {0, 0};
 #pragma unroll
             for (int comp = 0; comp < 2; comp++) {
-                const int q = comp ? A.q1 : A.q0;
+                const int q = (comp ? A.q1 : A.q0) < 0 ? -1 : (comp ? A.q1 : A.q0) + (int)blockIdx.y; // blockIdx.y = species
                 if (q >= 0) {
                     const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
                     plo[comp] = rs[rlo];
@@ -658,6 +659,10 @@ template <int N, int WG, int PRE, int MID, int POST, bool ST> hipError_t launch(
         const int g_lo = L / G_::R + 1, g_hi = (a.nrows - L) / G_::R;
         if (g_hi > g_lo) groups = g_lo + (a.nrows / G_::R - g_hi); // else: everything is live
         else { PassArgs b = a; b.live_rows_only = 0; hipLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, b); return hipGetLastError(); }
+    }
+    if constexpr (MID == MID_ATOMS) { // grid.y = species (q0 / q1 are those of species 0, the grids are species_stride apart)
+        hipLaunchKernelGGL(kern, dim3(groups, a.nspecies > 0 ? a.nspecies : 1), dim3(WGeo<WG>::THR), lds_bytes, st, a);
+        return hipGetLastError();
     }
     if (a.ev_start && a.ev_stop) {
         PassArgs b = a;
