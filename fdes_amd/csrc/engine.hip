@@ -85,7 +85,7 @@ struct fdes_plan {
     bool lanes_dirty = false;           // lanes hold partial sums not yet folded into lane 0
     std::vector<int> seg_h;             // host copy of the (slice, species) segment table of the current configuration
     int64_t slices_skipped = 0;
-    float2 *A = nullptr, *B = nullptr, *C = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
+    float2 *A = nullptr, *B = nullptr, *C = nullptr, *C2 = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
     float* GT = nullptr;
     bool tables_shared = false; // PT / GT belong to the parent plan (lanes)
     // hipGraph replay of the fused slice loop (option "graph"): the launch sequence of a configuration depends only on
@@ -284,7 +284,7 @@ int fused_slice(fdes_plan* pl, int s)
     // P4 (mask) and P6 (masked propagator): P4/P6 run only their live row groups, P3/P5 do not store the rows those
     // never read, P5 does not load the columns they never write (pre-zeroed at plan creation).
     const int md = m1 < m2 ? m1 : m2, band = md * md;
-    const int bs = c->band_skip ? 1 : 0;
+    const int bs = (c->band_skip && m1 == m2) ? 1 : 0; // the column classes of the passes assume the band of a square grid
     auto empty = [&](int q) { return q >= pl->p.m3 || pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ]; };
     const bool have_seg = !pl->seg_h.empty();
     if (have_seg && empty(s)) {
@@ -302,14 +302,17 @@ int fused_slice(fdes_plan* pl, int s)
         pl->slices_skipped++;
         return FDES_OK;
     }
-    // the pair's potential is needed by its first non-empty slice
-    if ((s & 1) == 0 || (have_seg && empty(s - 1))) RC(fused_potential_pair(pl, s & ~1));
-    PassArgs a3 = pass_x(pl);
-    a3.in0 = pl->B; a3.out = pl->C; a3.scale = pl->p.imPot;
-    a3.band = band; a3.skip_dead_stores = bs;
-    HIPCHK(c, lds_pass(m1, XF_INV, (s & 1) ? MID_EXPIV_IM : MID_EXPIV_RE, XF_FWD, true, a3, c->stream));
+    // the pair's potential and both transmission functions are built at the pair's first non-empty slice:
+    // C <- F_x[t_s0], C2 <- F_x[t_(s0+1)] from one read and one inverse transform of W = V_s0 + i V_(s0+1)
+    if ((s & 1) == 0 || (have_seg && empty(s - 1))) {
+        RC(fused_potential_pair(pl, s & ~1));
+        PassArgs a3 = pass_x(pl);
+        a3.in0 = pl->B; a3.out = pl->C; a3.out2 = pl->C2; a3.scale = pl->p.imPot;
+        a3.band = band; a3.skip_dead_stores = bs;
+        HIPCHK(c, lds_pass(m1, XF_INV, MID_EXPIV_PAIR, XF_FWD, true, a3, c->stream));
+    }
     PassArgs a4 = pass_y(pl);
-    a4.in0 = pl->C; a4.out = pl->E; a4.scale = 1.f / ((float)pl->m12); a4.mindim = md;
+    a4.in0 = (s & 1) ? pl->C2 : pl->C; a4.out = pl->E; a4.scale = 1.f / ((float)pl->m12); a4.mindim = md;
     a4.band = band; a4.live_rows_only = bs;
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, c->stream));
     PassArgs a5 = pass_x(pl);
@@ -350,7 +353,7 @@ int fused_leave(fdes_plan* pl, bool propagated)
 {
     PassArgs a = pass_x(pl);
     a.in0 = pl->PSIH; a.out = pl->PSI;
-    if (pl->ctx->band_skip && propagated) { // the dead columns were last written by fused_enter: they count as zero
+    if (pl->ctx->band_skip && pl->p.m1 == pl->p.m2 && propagated) { // the dead columns were last written by fused_enter: they count as zero
         const int md = pl->p.m1 < pl->p.m2 ? pl->p.m1 : pl->p.m2;
         a.band = md * md;
         a.skip_dead_loads = 1;
@@ -577,7 +580,7 @@ int fdes_plan_destroy(fdes_plan* pl)
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {pl->Z_d, pl->spec_d, pl->xyz0_d, pl->xyzTO_d, pl->xyzK_d, pl->xyzFP_d, pl->dwf_d, pl->occ_d, pl->bins.keys,
                     pl->bins.keys_sorted, pl->bins.vals, pl->bins.order, pl->bins.seg, pl->bins.tmp, pl->bins.recs, pl->bins.recs_sorted, pl->bins.rowstart, pl->D, pl->VH, pl->T, pl->PSI,
-                    pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A == pl->C ? nullptr : pl->A, pl->B, pl->C, pl->E, pl->PSIH,
+                    pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A == pl->C ? nullptr : pl->A, pl->C, pl->C2, pl->E, pl->PSIH,
                     pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT}; // F aliases C
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (auto& g : pl->graphs) (void)hipGraphExecDestroy(g.exec);
@@ -699,8 +702,8 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         if (c->pass_threads == 512) pl->wg = 512;
         else if ((c->pass_threads == 1 || c->pass_threads == 513 || (c->pass_threads == 0 && small)) && m1 <= 2048 && m2 <= 2048) pl->wg = 1;
         else pl->wg = ok256 ? 256 : 512;
-        // Slice-loop working set: the transient grids ping-pong between two buffers (A -> [P2] -> B; B -> [P3] -> C;
-        // C -> [P4] -> E; E, PSIH -> [P5] -> F; F -> [P6] -> PSIH, so A, C and F are never live together), and the
+        // Slice-loop working set: the transient grids share buffers (A -> [P2] -> B; B -> [P3] -> C, C2; C | C2 -> [P4] -> E;
+        // E, PSIH -> [P5] -> F; F -> [P6] -> PSIH: A, C and F are never live together, nor are B and E), and the
         // lanes share the read-only tables PT / GT: 4 grids per lane + the tables instead of 7.5 per lane, so that two
         // lanes at 2048^2 (304 MiB) mostly stay inside the 256 MiB Infinity Cache.  Dead (band-limited) rows of C / F
         // may hold stale data of the other tenant: P4 / P6 never read them.
@@ -708,8 +711,9 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         pl->F = pl->C;
         if (pl->nZ == 1) pl->A = pl->C;
         else PLCHK(dmalloc(c, &pl->A, pl->m12 * (size_t)pl->nZ));
-        PLCHK(dmalloc(c, &pl->B, pl->m12));
+        PLCHK(dmalloc(c, &pl->C2, pl->m12)); // x-spectrum of the transmission function of the pair's second slice
         PLCHK(dmalloc(c, &pl->E, pl->m12));
+        pl->B = pl->E; // the packed pair potential is consumed by P3 before P4 writes E
         PLCHK(dmalloc(c, &pl->PSIH, pl->m12));
         if (c->share_PT) { pl->PT = c->share_PT; pl->GT = c->share_GT; pl->tables_shared = true; }
         else {
@@ -718,7 +722,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         }
         PLCHK(dmalloc(c, &pl->bins.rowstart, (size_t)pl->p.m3 * pl->nZ * (size_t)(pl->p.m2 + 1)));
         // dead (band-limited) rows / columns of these grids are never written again: they must read as zero
-        for (float2* q : {pl->C, pl->E, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->m12, c->stream));
+        for (float2* q : {pl->C, pl->C2, pl->E, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->m12, c->stream));
         if (!pl->tables_shared) {
             PLHIP(k_build_propagator(pl->PT, pl->kp, 1, c->stream));
             for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 1, c->stream));

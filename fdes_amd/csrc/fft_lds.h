@@ -25,13 +25,15 @@ enum MidKind {
     MID_GTABN = 8,  // MID_GTAB with a species loop (nspecies > 1)
     MID_ATOMS = 9,  // source rows are built from the sorted atom records (re: slice q0, im: slice q1), no grid read
     MID_EXPIV_RE = 10, // t = exp(-scale * v) (cos v, sin v) with v = Re(row)  (two slices packed per potential grid)
-    MID_EXPIV_IM = 11  // ... v = Im(row)
+    MID_EXPIV_IM = 11, // ... v = Im(row)
+    MID_EXPIV_PAIR = 12 // both at once: out <- F_x[t(Re)], out2 <- F_x[t(Im)] (one read and one inverse transform for two slices)
 };
 
 struct PassArgs {
     const float2* in0 = nullptr;
     const float2* in1 = nullptr;
     float2* out = nullptr;
+    float2* out2 = nullptr;      // MID_EXPIV_PAIR: second output grid
     float2* zsrc = nullptr;      // MID_ZSRC: rows to clear (== in0)
     const float* gtab = nullptr; // MID_GTAB: [species][row][col]
     const float2* ptab = nullptr;

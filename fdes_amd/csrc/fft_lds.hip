@@ -304,6 +304,9 @@ __device__ __forceinline__ void xform(float2 (&a)[WGeo<WG>::NRV][16], float2* ld
 #endif
 // two-operand passes need the registers of two waves per SIMD
 constexpr int pass_waves(int mid) { return (mid == MID_MULPSI || mid == MID_GTABN) ? 2 : FDES_WAVES; }
+#ifndef FDES_PAIR_TWR
+#define FDES_PAIR_TWR 1 // register twiddles in the two-slice transmission pass (16 spilled registers at 2048, still +4 % over table fetches)
+#endif
 #ifndef FDES_P5_PREFETCH
 #define FDES_P5_PREFETCH 0 // requesting the second operand with the first: measured, no gain (A/B 12.1k vs 12.1k), 14 more VGPRs
 #endif
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
     using G_ = Geo<N, WG>;
     constexpr int T = G_::T, R = G_::R, RH = G_::RH;
     extern __shared__ float2 lds[];
-    constexpr bool TWR = (pass_waves(MID) == 2) && (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && MID != MID_PTAB && MID != MID_GTABN);
+    constexpr bool TWR = (pass_waves(MID) == 2) && (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && MID != MID_PTAB && MID != MID_GTABN && (MID != MID_EXPIV_PAIR || (FDES_PAIR_TWR && N <= 2048)));
     Tw tw;
     tw.g0 = reinterpret_cast<const float2*>(A.tw0);
     tw.g1 = reinterpret_cast<const float2*>(A.tw1);
@@ -396,9 +399,10 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
     float2* __restrict__ zsrc = A.zsrc ? reinterpret_cast<float2*>(A.zsrc) + gbase : nullptr;
     if constexpr (MID == MID_ATOMS) A.out += (size_t)blockIdx.y * A.species_stride; // one launch covers every species
-    float2* __restrict__ outn = reinterpret_cast<float2*>(A.out) + gbase;
 
     float2 a[WGeo<WG>::NRV][16];
+    float2 b[(MID == MID_MULPSI) ? WGeo<WG>::NRV : 1][16]; // second operand
+    float vim[(MID == MID_EXPIV_PAIR) ? WGeo<WG>::NRV : 1][16]; // potential of the second slice of a pair
     if constexpr (MID == MID_GTABN) {
         // sum over species in Fourier space, then one inverse transform (phaseGrating's species loop)
         float2 acc[WGeo<WG>::NRV][16];
@@ -527,7 +531,6 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
                 for (int l = 0; l < 16; l++) gvv[h][l] = gtab[rbase[h] + t + T * l];
         }
         // second operand of the product: requested with the first so that its HBM round trip overlaps the first transform
-        float2 b[(MID == MID_MULPSI) ? WGeo<WG>::NRV : 1][16];
         if constexpr (MID == MID_MULPSI && FDES_P5_PREFETCH) load_rows<N, WG>(b, in1, rbase, t, A.skip_dead_loads != 0);
         xform<N, WG, PRE, false, TWR>(a, lds, r, t, tw, gs);
         if constexpr (MID == MID_EXPIV) {
@@ -551,6 +554,20 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
                     float sn, cs;
                     sincos_cw(v, sn, cs);
                     a[h][l] = make_float2(e * cs, e * sn);
+                }
+        } else if constexpr (MID == MID_EXPIV_PAIR) {
+            // transmission function of the first slice now; the second slice's potential (one float per pixel) waits
+            // in registers until the first result has been transformed and stored
+#pragma unroll
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) {
+                    const float v0 = a[h][l].x;
+                    vim[h][l] = a[h][l].y;
+                    float sn, cs;
+                    const float e0 = __expf(-(v0 * A.scale));
+                    sincos_cw(v0, sn, cs);
+                    a[h][l] = make_float2(e0 * cs, e0 * sn);
                 }
         } else if constexpr (MID == MID_MASK) {
             // zeroHighFreq tests (float)(i1^2 + i2^2) * 9 / mindim^2 > 1 (src/multisliceSimulation.cu:241).  On the
@@ -601,39 +618,57 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
                 for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], b[h][l]); // f0 = t, f1 = psi
         }
     }
+    auto store_rows = [&](float2 (&v)[WGeo<WG>::NRV][16], float2* outp) {
+        if constexpr (!STORE_T) {
+            float2* __restrict__ on = outp + gbase;
+#pragma unroll
+            for (int h = 0; h < WGeo<WG>::NRV; h++)
+#pragma unroll
+                for (int l = 0; l < 16; l++) on[rbase[h] + t + T * l] = v[h][l];
+        } else {
+            // stage the R x N tile as [c][r] (swizzled) and write R contiguous elements per output row
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < WGeo<WG>::NRV; h++) {
+                const int rr = r + h * RH;
+#pragma unroll
+                for (int l = 0; l < 16; l++) {
+                    const int c = t + T * l;
+                    lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))] = v[h][l];
+                }
+            }
+            __syncthreads();
+            float2* __restrict__ dst = outp + row0; // transposed grid: N rows of length nrows
+            const unsigned ld = (unsigned)A.nrows;
+            const int rr = tid & (R - 1), c0 = tid / R; // WG is a multiple of R: rr is the same in every iteration
+#pragma unroll
+            for (int it = 0; it < WGeo<WG>::NRV * 16; it++) {
+                const int c = c0 + it * (WGeo<WG>::THR / R);
+                // wave-uniform: skip an iteration only when every column it covers ([it, it + 1) * WG / R) is dead
+                if (A.skip_dead_stores && dead_index(iwc(it * (WGeo<WG>::THR / R), N), A.band) &&
+                    dead_index(iwc(it * (WGeo<WG>::THR / R) + WGeo<WG>::THR / R - 1, N), A.band) &&
+                    (it * (WGeo<WG>::THR / R) > N / 2) == (it * (WGeo<WG>::THR / R) + WGeo<WG>::THR / R - 1 > N / 2))
+                    continue;
+                (dst + (size_t)(it * (WGeo<WG>::THR / R)) * ld)[(unsigned)c0 * ld + (unsigned)rr] = lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))];
+            }
+        }
+    };
     xform<N, WG, POST, (PRE != XF_NONE), TWR>(a, lds, r, t, tw, gs);
-
-    if constexpr (!STORE_T) {
+    store_rows(a, reinterpret_cast<float2*>(A.out));
+    if constexpr (MID == MID_EXPIV_PAIR) {
 #pragma unroll
         for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
-            for (int l = 0; l < 16; l++) outn[rbase[h] + t + T * l] = a[h][l];
-    } else {
-        // stage the R x N tile as [c][r] (swizzled) and write R contiguous elements per output row
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < WGeo<WG>::NRV; h++) {
-            const int rr = r + h * RH;
-#pragma unroll
             for (int l = 0; l < 16; l++) {
-                const int c = t + T * l;
-                lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))] = a[h][l];
+                const float v1 = vim[h][l];
+                float sn, cs;
+                const float e1 = __expf(-(v1 * A.scale));
+                sincos_cw(v1, sn, cs);
+                a[h][l] = make_float2(e1 * cs, e1 * sn);
             }
-        }
-        __syncthreads();
-        float2* __restrict__ dst = reinterpret_cast<float2*>(A.out) + row0; // transposed grid: N rows of length nrows
-        const unsigned ld = (unsigned)A.nrows;
-        const int rr = tid & (R - 1), c0 = tid / R; // WG is a multiple of R: rr is the same in every iteration
-#pragma unroll
-        for (int it = 0; it < WGeo<WG>::NRV * 16; it++) {
-            const int c = c0 + it * (WGeo<WG>::THR / R);
-            // wave-uniform: skip an iteration only when every column it covers ([it, it + 1) * WG / R) is dead
-            if (A.skip_dead_stores && dead_index(iwc(it * (WGeo<WG>::THR / R), N), A.band) &&
-                dead_index(iwc(it * (WGeo<WG>::THR / R) + WGeo<WG>::THR / R - 1, N), A.band) &&
-                (it * (WGeo<WG>::THR / R) > N / 2) == (it * (WGeo<WG>::THR / R) + WGeo<WG>::THR / R - 1 > N / 2))
-                continue;
-            (dst + (size_t)(it * (WGeo<WG>::THR / R)) * ld)[(unsigned)c0 * ld + (unsigned)rr] = lds[c * R + ((rr + (c >> G_::SH)) & (R - 1))];
-        }
+        __syncthreads(); // every wave is done with the transpose tile before the second transform writes the row buffers
+        xform<N, WG, POST, true, TWR>(a, lds, r, t, tw, gs);
+        store_rows(a, reinterpret_cast<float2*>(A.out2));
     }
 }
 
@@ -689,6 +724,7 @@ template <int N, int WG> hipError_t dispatch(int pre, int mid, int post, bool st
     CASE(XF_FWD, MID_ATOMS, XF_NONE, true)   // P1': atom records -> x spectrum of two slices (re / im)
     CASE(XF_INV, MID_EXPIV_RE, XF_FWD, true) // P3 on the real / imaginary component of a packed potential
     CASE(XF_INV, MID_EXPIV_IM, XF_FWD, true)
+    CASE(XF_INV, MID_EXPIV_PAIR, XF_FWD, true) // P3 for both slices of a packed potential
     CASE(XF_FWD, MID_GTAB, XF_INV, true)     // P2: y FFT * f_e/sinc, y IFFT (one species)
     CASE(XF_FWD, MID_GTABN, XF_INV, true)    // P2: y FFT * f_e/sinc, species sum, y IFFT
     CASE(XF_INV, MID_EXPIV, XF_FWD, true)    // P3: x IFFT, exp(iV), x FFT
