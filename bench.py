@@ -197,7 +197,7 @@ def main():
             # bytes the fused loop moves per pixel and slice (P1'/2 + P2/2 + P3 + P4 + P5 + P6 =
             # 4 + 10 + 13.3 + 10.7 + 16 + 16, dead band-limit rows/columns not counted) at the measured rate, and the same
             # rate priced with SURVEY 8d's model of separate FFT passes ((176 + 56 nZ) B/px; may exceed the HBM peak)
-            "engine_bytes_per_px_slice": 70, "engine_GBps": round(70 * px * (value / world) / 1e9, 1),
+            "engine_bytes_per_px_slice": 66, "engine_GBps": round(66 * px * (value / world) / 1e9, 1),
             "survey_full_step_model_GBps": round((176 + 56 * 1) * px * (value / world) / 1e9, 1),
             "lane_slice_loop_ms_per_slice": round(loop_ms / max(loop_slices, 1), 5),
             "slice_loop": "fused LDS passes" if fused else "rocFFT + point-wise kernels",
