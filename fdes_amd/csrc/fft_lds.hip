@@ -47,15 +47,25 @@ template <bool INV> __device__ __forceinline__ float2 mul_mi(float2 a) { return 
 // b + (-i) a (forward) / b + i a (inverse), and b - (...): one packed fma each, the swap rides on op_sel
 template <bool INV> __device__ __forceinline__ float2 add_mi(float2 b, float2 a) { return __builtin_elementwise_fma(a.yx, (INV ? cf{-1.f, 1.f} : cf{1.f, -1.f}), b); }
 template <bool INV> __device__ __forceinline__ float2 sub_mi(float2 b, float2 a) { return __builtin_elementwise_fma(a.yx, (INV ? cf{1.f, -1.f} : cf{-1.f, 1.f}), b); }
-// 3-multiply complex product of the reference (src/complexMath.cu:44-62): f0 = (a, b), f1 = (c, d)
+// Product t * psi and psi * P (multiplyElementwise, src/complexMath.cu:44-62).  The reference uses the 3-multiply form
+// k = a (c + d), re = k - d (a + b), im = k + c (b - a): 8 dependent scalar operations per pixel.  The default here is
+// the 4-multiply form as one packed multiply + one packed FMA (2 instructions; no worse conditioned than the 3-multiply
+// form, which cancels k against its partner); -DFDES_CMUL3=1 restores the reference's operation order.
+#ifndef FDES_CMUL3
+#define FDES_CMUL3 0
+#endif
 __device__ __forceinline__ float2 cmul3(float2 f0, float2 f1)
 {
+#if FDES_CMUL3
     const float a = f0.x, b = f0.y;
     float c = f1.x, d = f1.y;
     const float k = a * (c + d);
     d *= a + b;
     c *= b - a;
     return make_float2(k - d, k + c);
+#else
+    return cmul(f0, f1);
+#endif
 }
 
 template <bool INV> __device__ __forceinline__ void r2(float2& x0, float2& x1)
