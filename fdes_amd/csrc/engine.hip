@@ -737,7 +737,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     // hardware queues; which lanes end up sharing one is not under our control), and only thrashes the Infinity Cache
     // at 2048^2.
     const int nlanes = c->lanes > 0 ? c->lanes : 2;
-    if (pl->fused && nlanes > 1 && !c->is_lane_ctx) {
+    if (nlanes > 1 && !c->is_lane_ctx) {
         for (int l = 1; l < nlanes; l++) {
             fdes_ctx* lc = nullptr;
             PLCHK(fdes_create(&lc, c->device));
