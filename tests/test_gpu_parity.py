@@ -354,3 +354,52 @@ def test_c5_size_propagation_properties(engine):
     print("[parity] 4096^2 linearity residual:", lin, "norm drift over 3 free-space steps:", drift)
     assert lin < 5e-6 and drift < 1e-5
     pl.close()
+
+
+def _edge_case(kind):
+    fused = kind.startswith("fused_")      # 256^2: hand-written passes; 64^2: generic rocFFT path
+    kind = kind.replace("fused_", "")
+    hp, at = S.case_tiny(m=256 if fused else 64, m3=4, nz=2, nat=60, seed=11)
+    xyz = at.xyz.copy()
+    d, m = hp.c.d1, (256 if fused else 64)
+    if kind == "outside":
+        # atoms beyond the lateral window (both sides), above the first and below the last slice, and exactly on the
+        # slice boundaries and on the window edge
+        xyz[0] = (0.9 * m * d, 0.0, 0.0)
+        xyz[1] = (-0.9 * m * d, 0.2 * m * d, 0.0)
+        xyz[2] = (0.0, 0.75 * m * d, 0.0)
+        xyz[3] = (0.0, 0.0, 9.0e-10)
+        xyz[4] = (0.0, 0.0, -9.0e-10)
+        xyz[5] = (0.5 * m * d, 0.5 * m * d, 1.0e-10)
+        xyz[6] = (-0.5 * m * d, -0.5 * m * d, -1.0e-10)
+        xyz[7] = (0.0, 0.0, 2.0e-10)
+        xyz[8] = (0.0, 0.0, -2.0e-10)
+    if kind == "stacked":
+        xyz[:30, :2] = xyz[0, :2]          # thirty atoms in one column: same pixels in every slice they fall into
+    at = fdes_amd.HostAtoms(at.Z, xyz, at.dwf, at.occ)
+    if kind == "one_slice":
+        hp.set(m3=1)
+    if kind == "no_atoms":
+        at = fdes_amd.HostAtoms(at.Z[:0], xyz[:0], at.dwf[:0], at.occ[:0])
+    if kind == "one_atom":
+        at = fdes_amd.HostAtoms(at.Z[:1], xyz[:1] * 0, at.dwf[:1], at.occ[:1])
+    return hp, at
+
+
+@pytest.mark.parametrize("kind", ["outside", "fused_outside", "stacked", "fused_stacked", "one_slice", "fused_one_slice", "no_atoms",
+                                  "fused_no_atoms", "one_atom", "fused_one_atom"])
+def test_edge_cases_match_the_oracle(engine, oracle, kind):
+    """Inputs at the edges of the domain: atoms outside the window / the slice range / on boundaries, many atoms on one
+    pixel (colliding deposits), a single slice, a single atom, no atom at all (free-space propagation)."""
+    hp, at = _edge_case(kind)
+    fdes_amd.consistent(hp)
+    out = engine.build_measurements(hp, at, want_potential=True)
+    ref = oracle.build_measurements(hp, at, prec="f64", want_potential=True)
+    pot = out["potential"][..., 0] + 1j * out["potential"][..., 1]
+    rpot = ref["potential"][..., 0] + 1j * ref["potential"][..., 1]
+    if np.abs(rpot).max() > 0:
+        check(pot, rpot, None, 2e-5, f"edge case {kind}: potential stack")
+    else:
+        assert np.abs(pot).max() == 0
+    check(out["image"], ref["image"], None, 1e-5, f"edge case {kind}: image")
+    assert np.isfinite(out["image"]).all()
