@@ -522,7 +522,12 @@ int fdes_gpu_available(void)
     return n > 0;
 }
 
-int fdes_create(fdes_ctx** out, int gpu_index)
+namespace {
+// prio_class: 0 = default priority; 1 / 2 = the greatest / least stream priority of the device.  HIP multiplexes
+// streams of one priority onto a few hardware queues, and two lanes that land on the same queue run one after the
+// other; streams of different priority use different queues (measured: three lanes at 1024^2, three species:
+// 20.5 k/s with equal priorities, 30.9 k/s with distinct ones).
+int create_ctx(fdes_ctx** out, int gpu_index, int prio_class)
 {
     if (!out) return FDES_EINVAL;
     *out = nullptr;
@@ -530,7 +535,16 @@ int fdes_create(fdes_ctx** out, int gpu_index)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || gpu_index < 0 || gpu_index >= n) { (void)hipGetLastError(); return FDES_EGPU; }
     fdes_ctx* c = new fdes_ctx();
     c->device = gpu_index;
-    if (hipSetDevice(gpu_index) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    bool ok = hipSetDevice(gpu_index) == hipSuccess;
+    if (ok && prio_class > 0) {
+        int least = 0, greatest = 0;
+        ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+             hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_class == 1 ? greatest : least) == hipSuccess;
+    } else if (ok) {
+        ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
         delete c;
         return FDES_EGPU;
     }
@@ -538,6 +552,9 @@ int fdes_create(fdes_ctx** out, int gpu_index)
     *out = c;
     return FDES_OK;
 }
+} // namespace
+
+int fdes_create(fdes_ctx** out, int gpu_index) { return create_ctx(out, gpu_index, 0); }
 
 int fdes_destroy(fdes_ctx* c)
 {
@@ -732,15 +749,15 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLHIP(hipMemcpyAsync(pl->xyzTO_d, pl->xyz0_d, sizeof(float) * n3f, hipMemcpyDeviceToDevice, c->stream));
     PLCHK(tilt_coordinates(pl, pl->xyzTO_d, pl->p.tilt_offset_x, pl->p.tilt_offset_y, pl->p.tilt_offset_z));
     PLHIP(hipStreamSynchronize(c->stream));
-    // lanes hide the gap between dependent kernels of one stream (about 8 us on this part).  Two by default: a third
-    // lane helps one-species 1024^2 runs (+12 %) but costs three-species ones 19 % (HIP maps streams onto a few
-    // hardware queues; which lanes end up sharing one is not under our control), and only thrashes the Infinity Cache
-    // at 2048^2.
-    const int nlanes = c->lanes > 0 ? c->lanes : 2;
+    // lanes hide the gap between dependent kernels of one stream (about 8 us on this part): three up to 1024^2, where
+    // the kernels are no longer than that gap (each lane on a stream of its own priority class, see create_ctx), two
+    // above (a third lane only thrashes the Infinity Cache at 2048^2; equal priorities there: a high-priority lane
+    // starves the other one of workgroup slots, -1.5 %).
+    const int nlanes = c->lanes > 0 ? c->lanes : (pl->m12 <= (size_t)1024 * 1024 ? 3 : 2);
     if (nlanes > 1 && !c->is_lane_ctx) {
         for (int l = 1; l < nlanes; l++) {
             fdes_ctx* lc = nullptr;
-            PLCHK(fdes_create(&lc, c->device));
+            PLCHK(create_ctx(&lc, c->device, nlanes >= 3 ? (l <= 2 ? l : 0) : 0));
             lc->is_lane_ctx = true;
             lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip;
             lc->share_PT = pl->PT; lc->share_GT = pl->GT; // read-only tables of the parent plan (built and synchronised above)

@@ -1,0 +1,23 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+import torch, fdes_amd
+from tests import specimens as S
+hp, at = S.case_tiny(m=256, m3=6, nz=2, frPh=2, n3=2, tilt=True, zfrac=0.3)
+fdes_amd.consistent(hp)
+free0 = None
+for it in range(25):
+    eng = fdes_amd.Engine(0)
+    out = eng.build_measurements(hp, at)
+    pl = eng.plan(hp, at)
+    pl.begin_measurement(0)
+    for j in range(4):
+        pl.run_config(0, j, 0.25)
+    pl.end_measurement(0)
+    pl.sync()
+    pl.close()
+    eng.close() if hasattr(eng, "close") else None
+    del eng
+    f, t = torch.cuda.mem_get_info()
+    if it == 2: free0 = f
+    if it % 6 == 0: print(it, "free MiB", f >> 20)
+print("leak MiB over 22 iterations:", (free0 - f) >> 20)
