@@ -231,11 +231,28 @@ int phase_grating(fdes_plan* pl, const float* xyz, const BinGeom& g, int s)
     return FDES_OK;
 }
 
-// forwardPropagation, src/multisliceSimulation.cu:538-549 (V in VH)
-int forward_propagation(fdes_plan* pl)
+// Packed potential of the slice pair (s0, s0 + 1) on the generic path: W = V_s0 + i V_(s0+1) in VH from one forward
+// transform per species and one inverse transform for two slices (the deposits are real, the filter is real and
+// even), with the filter read from the per-plan table instead of being re-evaluated (3 expf + 2 sinf per pixel).
+int phase_grating_pair(fdes_plan* pl, const float* xyz, const BinGeom& g, int s0)
 {
     fdes_ctx* c = pl->ctx;
-    HIPCHK(c, k_transmit(pl->T, pl->VH, pl->m12, c->stream));
+    for (int z = 0; z < pl->nZ; z++) {
+        const int k0 = s0 * pl->nZ + z, k1 = (s0 + 1 < g.m3) ? (s0 + 1) * pl->nZ + z : -1;
+        HIPCHK(c, geom_deposit_pair(pl->D, xyz, pl->occ_d, pl->bins, k0, k1, g, pl->deposit_blocks, c->stream));
+        HIPCHK(c, fft_exec(pl, pl->D, false, c->stream));
+        HIPCHK(c, k_filter_accum_tab(pl->VH, pl->D, pl->GT + (size_t)z * pl->m12, pl->m12, z == 0, c->stream));
+    }
+    HIPCHK(c, fft_exec(pl, pl->VH, true, c->stream));
+    return FDES_OK;
+}
+
+// forwardPropagation, src/multisliceSimulation.cu:538-549 (V in VH; comp >= 0: component of the packed pair potential)
+int forward_propagation(fdes_plan* pl, int comp = -1)
+{
+    fdes_ctx* c = pl->ctx;
+    if (comp >= 0) HIPCHK(c, k_transmit_comp(pl->T, pl->VH, pl->m12, comp, pl->p.imPot, c->stream));
+    else HIPCHK(c, k_transmit(pl->T, pl->VH, pl->m12, c->stream));
     RC(bandwidth_limit(pl, pl->T));
     HIPCHK(c, k_mul(pl->PSI, pl->T, pl->PSI, pl->m12, c->stream));      // multiplyElementwise(t, psi)
     HIPCHK(c, fft_exec(pl,pl->PSI, false, c->stream));                  // convolveWithFrProp
@@ -443,8 +460,8 @@ int slice_loop(fdes_plan* pl, int nslices)
         return FDES_OK;
     }
     for (int s = 0; s < nslices; s++) {
-        RC(phase_grating(pl, pl->xyzFP_d, g, s));
-        RC(forward_propagation(pl));
+        if ((s & 1) == 0) RC(phase_grating_pair(pl, pl->xyzFP_d, g, s));
+        RC(forward_propagation(pl, s & 1));
     }
     return FDES_OK;
 }
@@ -708,6 +725,10 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     }
     PLHIP(k_build_propagator(pl->P, pl->kp, 0, c->stream));
     pl->fused = pl->fft->backend == 2;
+    if (!pl->fused) { // filter table of the generic path (natural layout)
+        PLCHK(dmalloc(c, &pl->GT, pl->m12 * (size_t)pl->nZ));
+        for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 0, c->stream));
+    }
     if (pl->fused) {
         const int m1 = pl->p.m1, m2 = pl->p.m2;
         const bool ok256 = (m2 % lds_fft_rows_per_block(m1, 256) == 0) && (m1 % lds_fft_rows_per_block(m2, 256) == 0) &&

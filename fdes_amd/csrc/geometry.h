@@ -35,5 +35,8 @@ hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, const float* oc
 hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key, const BinGeom& g,
                         float imPot, int blocks, hipStream_t st);
 
+hipError_t geom_deposit_pair(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key0, int key1, const BinGeom& g,
+                             int blocks, hipStream_t st);
+
 } // namespace fdes
 #endif

@@ -139,6 +139,35 @@ __global__ void k_deposit(float2* __restrict__ V, const float* __restrict__ xyz,
     }
 }
 
+// Deposit of a slice PAIR for the packed potential W = V_s0 + i V_s1 (the deposits are real): blockIdx.y = component,
+// key0 / key1 = its (slice, species) segment or -1.  No absorptive part here: it is imPot * V at transmission time.
+__global__ void k_deposit_pair(float2* __restrict__ V, const float* __restrict__ xyz, const float* __restrict__ occ,
+                               const uint32_t* __restrict__ order, const int* __restrict__ seg, int key0, int key1, BinGeom g)
+{
+    const int comp = (int)blockIdx.y, key = comp ? key1 : key0;
+    if (key < 0) return;
+    const int beg = seg[key], end = seg[key + 1];
+    float* f = reinterpret_cast<float*>(V) + comp;
+    for (int p = beg + blockIdx.x * blockDim.x + threadIdx.x; p < end; p += gridDim.x * blockDim.x) {
+        const int i = (int)order[p];
+        const float x1 = xyz[i * 3 + 0] / g.d1 + ((float)g.m1) * 0.5f - 0.5f;
+        const float x2 = xyz[i * 3 + 1] / g.d2 + ((float)g.m2) * 0.5f - 0.5f;
+        int i1 = (int)roundf(x1);
+        int i2 = (int)roundf(x2);
+        const float r1 = x1 - (float)i1;
+        const float r2 = x2 - (float)i2;
+        const float a1 = fabsf(r1), a2 = fabsf(r2), oc = occ[i];
+        const int s1 = signum(r1), s2 = signum(r2);
+        atomicAdd(f + 2 * ((size_t)i2 * g.m1 + i1), (1 - a1) * (1 - a2) * oc);
+        i2 += s2;
+        atomicAdd(f + 2 * ((size_t)i2 * g.m1 + i1), (1 - a1) * a2 * oc);
+        i1 += s1;
+        atomicAdd(f + 2 * ((size_t)i2 * g.m1 + i1), a1 * a2 * oc);
+        i2 -= s2;
+        atomicAdd(f + 2 * ((size_t)i2 * g.m1 + i1), a1 * (1 - a2) * oc);
+    }
+}
+
 static inline int blocks_for(int n, int bs, int cap) { int b = (n + bs - 1) / bs; if (b < 1) b = 1; return b > cap ? cap : b; }
 
 hipError_t geom_srot(float* xyz, int nAt, int ax, int ay, float c, float s, hipStream_t st)
@@ -199,6 +228,13 @@ hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const Ato
                         float imPot, int blocks, hipStream_t st)
 {
     hipLaunchKernelGGL(k_deposit, dim3(blocks), dim3(256), 0, st, V, xyz, occ, b.order, b.seg, key, g, imPot);
+    return hipGetLastError();
+}
+
+hipError_t geom_deposit_pair(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key0, int key1, const BinGeom& g,
+                             int blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_deposit_pair, dim3(blocks, 2), dim3(256), 0, st, V, xyz, occ, b.order, b.seg, key0, key1, g);
     return hipGetLastError();
 }
 

@@ -25,6 +25,8 @@ hipError_t k_scale(float2* f, size_t n, float alpha, hipStream_t st);
 hipError_t k_axpy(float2* y, const float2* x, size_t n, float alpha, hipStream_t st);
 // Vhat = (first ? 0 : Vhat) + Dhat * g_Z(q) ; Dhat = 0   (projectedPotential_d * divideBySinc * multiplyWith...)
 hipError_t k_filter_accum(float2* Vhat, float2* Dhat, const KP& p, const Kirk& kz, int first, hipStream_t st);
+hipError_t k_filter_accum_tab(float2* Vhat, float2* Dhat, const float* G, size_t n, int first, hipStream_t st);
+hipError_t k_transmit_comp(float2* t, const float2* W, size_t n, int comp, float imPot, hipStream_t st);
 hipError_t k_transmit(float2* t, const float2* V, size_t n, hipStream_t st);
 hipError_t k_pick_potential(float2* V, const float2* W, size_t n, int comp, float imPot, hipStream_t st);
 hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st);

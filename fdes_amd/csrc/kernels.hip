@@ -88,6 +88,35 @@ __global__ void kk_filter_accum(float2* __restrict__ Vh, float2* __restrict__ Dh
     }
 }
 
+// Vh (+)= G * Dh with the tabulated filter (kk_gtab, natural layout); Dh is cleared for the next deposit
+__global__ void kk_filter_accum_tab(float2* __restrict__ Vh, float2* __restrict__ Dh, const float* __restrict__ G, size_t n, int first)
+{
+    GS_LOOP(i, n)
+    {
+        const float g = G[i];
+        const float2 d = Dh[i];
+        float2 v = first ? make_float2(0.f, 0.f) : Vh[i];
+        v.x += d.x * g;
+        v.y += d.y * g;
+        Vh[i] = v;
+        Dh[i] = make_float2(0.f, 0.f);
+    }
+}
+
+// potential2Transmission on one component of a packed pair potential: v = Re or Im, absorption imPot * v
+__global__ void kk_transmit_comp(float2* __restrict__ t, const float2* __restrict__ W, size_t n, int comp, float imPot)
+{
+    GS_LOOP(i, n)
+    {
+        const float2 w = W[i];
+        const float v = comp ? w.y : w.x;
+        const float a = expf(-(v * imPot));
+        float s, c;
+        sincosf(v, &s, &c);
+        t[i] = make_float2(a * c, a * s);
+    }
+}
+
 // Same filter as kk_filter_accum, tabulated once per plan and species (it does not depend on the
 // slice): g_Z(q) = f_e(q^2) * 4.78776452e-9 sigma / (d1 d2 m12) * x/sin x * y/sin y.
 __global__ void kk_gtab(float* __restrict__ G, KP p, Kirk kz, int transposed)
@@ -440,6 +469,8 @@ hipError_t k_filter_accum(float2* Vh, float2* Dh, const KP& p, const Kirk& kz, i
     LAUNCH(kk_filter_accum, (size_t)p.m1 * p.m2, st, Vh, Dh, p, kz, first);
 }
 hipError_t k_transmit(float2* t, const float2* V, size_t n, hipStream_t st) { LAUNCH(kk_transmit, n, st, t, V, n); }
+hipError_t k_transmit_comp(float2* t, const float2* W, size_t n, int comp, float imPot, hipStream_t st) { LAUNCH(kk_transmit_comp, n, st, t, W, n, comp, imPot); }
+hipError_t k_filter_accum_tab(float2* Vh, float2* Dh, const float* G, size_t n, int first, hipStream_t st) { LAUNCH(kk_filter_accum_tab, n, st, Vh, Dh, G, n, first); }
 hipError_t k_pick_potential(float2* V, const float2* W, size_t n, int comp, float imPot, hipStream_t st) { LAUNCH(kk_pick_potential, n, st, V, W, n, comp, imPot); }
 hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st)
 {
