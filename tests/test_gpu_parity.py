@@ -403,3 +403,23 @@ def test_edge_cases_match_the_oracle(engine, oracle, kind):
         assert np.abs(pot).max() == 0
     check(out["image"], ref["image"], None, 1e-5, f"edge case {kind}: image")
     assert np.isfinite(out["image"]).all()
+
+
+def test_shipped_si001_example_through_the_cli(oracle, tmp_path):
+    """The reference's ExampleSpecimens/Si_001_11k_cnf/dataFDES_11k.cnf (11 552 Si atoms, 1000^2 wave = 2^3 5^3 points
+    per side, 205 slices of 0.1 A, 100 kV, no aperture cut) through the FDES command line and the bug-compatible
+    .cnf reader: rocFFT path with the packed pair potential, Measurements.bin against the float32 oracle."""
+    import subprocess
+    src = os.path.join(G, "dataFDES_Si001_11k.cnf")
+    exe = os.path.abspath(os.path.join(os.path.dirname(G), "..", "fdes_amd", "csrc", "FDES"))
+    r = subprocess.run([exe, "--input_name", src, "--image_name", "Measurements.bin", "--emd_name", "results.emd"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    hp, at = fdes_amd.read_cnf(src)
+    assert (hp.c.m1, hp.c.m2, hp.c.m3, hp.c.n1) == (1000, 1000, 205, 660) and at.n in (11552, 11553)  # +1: duplicated last atom quirk
+    img = np.fromfile(tmp_path / "Measurements.bin", np.float32).reshape(1, 660, 660)
+    ref = oracle.build_measurements(hp, at, prec="f32")["image"]
+    e = relerr(img, ref)
+    print("[parity] Si[001] 11k CLI (1000^2 x 205 slices): E(gpu vs cpu_f32) =", e, "contrast", ref.std() / ref.mean())
+    assert ref.std() / ref.mean() > 1e-2
+    assert e < 5e-5
