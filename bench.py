@@ -199,6 +199,7 @@ def main():
             # rate priced with SURVEY 8d's model of separate FFT passes ((176 + 56 nZ) B/px; may exceed the HBM peak)
             "engine_bytes_per_px_slice": 66, "engine_GBps": round(66 * px * (value / world) / 1e9, 1),
             "survey_full_step_model_GBps": round((176 + 56 * 1) * px * (value / world) / 1e9, 1),
+            "survey_propagation_unit_model_GBps": round(80 * px * (value / world) / 1e9, 1),
             "lane_slice_loop_ms_per_slice": round(loop_ms / max(loop_slices, 1), 5),
             "slice_loop": "fused LDS passes" if fused else "rocFFT + point-wise kernels",
             "roofline": roof, "cpu_baseline": cpu, "finite": finite,

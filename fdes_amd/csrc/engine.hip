@@ -1048,6 +1048,31 @@ int fdes_plan_propagate_dev(fdes_plan* pl, void* psi_dev, const void* t_dev, int
     if (!pl || !psi_dev || !t_dev || batch < 1) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
+    if (pl->fused) {
+        // The propagation unit psi <- F^-1[P F[t psi]] as three row passes (SURVEY 8d's 80 B/px unit; here 24 + 24 + 16
+        // = 64 B/px before band-limit bookkeeping): rows y: t psi, FFT_x -> [kx][y]; rows kx: FFT_y, P, IFFT_y -> [y][kx];
+        // rows y: IFFT_x.  The x round trip is unnormalised (m1) and P carries 1 / (m1 m2): the last pass scales by 1.
+        const int m1 = pl->p.m1, m2 = pl->p.m2;
+        const int md = m1 < m2 ? m1 : m2, band = md * md;
+        const int bs = (c->band_skip && m1 == m2) ? 1 : 0;
+        for (int b = 0; b < batch; b++) {
+            float2* psi = (float2*)psi_dev + (size_t)b * pl->m12;
+            const float2* t = (const float2*)t_dev + (t_per_wave ? (size_t)b * pl->m12 : 0);
+            PassArgs a5 = pass_x(pl);
+            a5.in0 = t; a5.in1 = psi; a5.out = pl->F;
+            a5.band = band; a5.skip_dead_stores = bs;
+            HIPCHK(c, lds_pass(m1, XF_NONE, MID_MULPSI, XF_FWD, true, a5, c->stream));
+            PassArgs a6 = pass_y(pl);
+            a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->E;
+            a6.band = band; a6.live_rows_only = bs;
+            HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
+            PassArgs a7 = pass_x(pl);
+            a7.in0 = pl->E; a7.out = psi; a7.scale = 1.f;
+            if (bs) { a7.band = band; a7.skip_dead_loads = 1; } // dead kx columns of E are never written: they count as zero
+            HIPCHK(c, lds_pass(m1, XF_INV, MID_SCALE, XF_NONE, false, a7, c->stream));
+        }
+        return FDES_OK;
+    }
     for (int b = 0; b < batch; b++) {
         float2* psi = (float2*)psi_dev + (size_t)b * pl->m12;
         const float2* t = (const float2*)t_dev + (t_per_wave ? (size_t)b * pl->m12 : 0);

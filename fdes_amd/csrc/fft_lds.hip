@@ -740,6 +740,7 @@ template <int N, int WG> hipError_t dispatch(int pre, int mid, int post, bool st
     CASE(XF_INV, MID_EXPIV, XF_FWD, true)    // P3: x IFFT, exp(iV), x FFT
     CASE(XF_FWD, MID_MASK, XF_INV, true)     // P4: y FFT, band limit, y IFFT
     CASE(XF_INV, MID_MULPSI, XF_FWD, true)   // P5: x IFFT of t and psi, product, x FFT
+    CASE(XF_NONE, MID_MULPSI, XF_FWD, true)  // stand-alone propagation unit: product of two real-space grids, x FFT
     CASE(XF_FWD, MID_PTAB, XF_INV, true)     // P6: y FFT, * propagator, y IFFT
 #undef CASE
     return hipErrorInvalidValue;
