@@ -232,7 +232,8 @@ def cpu_baseline(hp, atoms, m):
     from tests import oracle_py
     q, _ = oracle_py.sub_sliced(hp)
     cores = oracle_py.get_threads()
-    ns = 2 if m >= 4096 else (6 if m >= 2048 else 24)
+    # about 15 s of CPU work: the oracle runs ~13 slices/s at 2048^2 and ~3 slices/s at 4096^2 on 16 threads
+    ns = min(int(q.c.m3), 48 if m >= 4096 else (192 if m >= 2048 else 512))
     oracle_py.wave(q, atoms, 0, 0, nslices=1)  # warm (FFT plans, page faults)
     t0 = time.perf_counter()
     oracle_py.wave(q, atoms, 0, 0, nslices=ns)
