@@ -88,9 +88,15 @@ struct fdes_plan {
     float2 *A = nullptr, *B = nullptr, *C = nullptr, *C2 = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
     float* GT = nullptr;
     bool tables_shared = false; // PT / GT belong to the parent plan (lanes)
+    // P^n tables for runs of n empty slices (skip_empty): built on first use on this plan's stream, least recently used
+    // of 6 replaced
+    struct PowTab { int n; float2* tab; uint64_t used; };
+    std::vector<PowTab> pow_tabs;
+    uint64_t pow_tick = 0;
     // hipGraph replay of the fused slice loop (option "graph"): the launch sequence of a configuration depends only on
     // the number of slices and on which slices are empty, so an instantiated graph is kept per such pattern
-    struct LoopGraph { uint64_t key; hipGraphExec_t exec; int64_t skipped; uint64_t used; };
+    struct LoopGraph { uint64_t key; hipGraphExec_t exec; int64_t skipped; uint64_t used; std::vector<std::pair<int, float2*>> pow; };
+    std::vector<std::pair<int, float2*>>* capture_pow = nullptr; // P^n tables of the graph being captured (built by its own nodes)
     std::vector<LoopGraph> graphs;
     uint64_t graph_tick = 0;
     bool capturing = false;
@@ -293,8 +299,43 @@ int fused_potential_pair(fdes_plan* pl, int s0)
     return FDES_OK;
 }
 
-int fused_slice(fdes_plan* pl, int s)
+// table of P^n (n >= 2) for a run of empty slices
+int propagator_pow(fdes_plan* pl, int n, float2** out)
 {
+    fdes_ctx* c = pl->ctx;
+    if (pl->capture_pow) {
+        // inside a graph capture the table belongs to that graph: its build kernel is one of the nodes, so every replay
+        // refreshes it and nothing depends on what other patterns did to a shared cache in between
+        for (auto& e : *pl->capture_pow)
+            if (e.first == n) { *out = e.second; return FDES_OK; }
+        float2* t = nullptr;
+        RC(dmalloc(c, &t, pl->m12));
+        pl->capture_pow->push_back({n, t});
+        HIPCHK(c, k_build_propagator_pow(t, pl->kp, 1, n, c->stream));
+        *out = t;
+        return FDES_OK;
+    }
+    for (auto& e : pl->pow_tabs)
+        if (e.n == n) { e.used = ++pl->pow_tick; *out = e.tab; return FDES_OK; }
+    float2* tab = nullptr;
+    if (pl->pow_tabs.size() >= 6) {
+        size_t lru = 0;
+        for (size_t i = 1; i < pl->pow_tabs.size(); i++) if (pl->pow_tabs[i].used < pl->pow_tabs[lru].used) lru = i;
+        tab = pl->pow_tabs[lru].tab; // stream order makes the overwrite safe: its last reader was enqueued earlier
+        pl->pow_tabs.erase(pl->pow_tabs.begin() + (long)lru);
+    } else {
+        RC(dmalloc(c, &tab, pl->m12));
+    }
+    HIPCHK(c, k_build_propagator_pow(tab, pl->kp, 1, n, c->stream));
+    pl->pow_tabs.push_back({n, tab, ++pl->pow_tick});
+    *out = tab;
+    return FDES_OK;
+}
+
+// one slice of the fused loop; *consumed = slices advanced (a run of empty slices is one Fresnel step with P^n)
+int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
+{
+    *consumed = 1;
     fdes_ctx* c = pl->ctx;
     const int m1 = pl->p.m1, m2 = pl->p.m2;
     // 2/3 band limit: rows/columns whose own frequency index already fails 9 i^2 <= mindim^2 are exact zeros after
@@ -312,11 +353,16 @@ int fused_slice(fdes_plan* pl, int s)
         a5.scale = (float)m1; // P5 hands m1 * FFT_x(t psi) to P6 (unnormalised x round trip); exact power of two
         a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
         HIPCHK(c, lds_pass(m1, XF_NONE, MID_SCALE, XF_NONE, true, a5, c->stream));
+        int run = 1;
+        while (s + run < nslices && empty(s + run)) run++;
+        float2* ptab = pl->PT;
+        if (run > 1) RC(propagator_pow(pl, run, &ptab));
         PassArgs a6 = pass_y(pl);
-        a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->PSIH;
+        a6.in0 = pl->F; a6.ptab = ptab; a6.out = pl->PSIH;
         a6.band = band; a6.live_rows_only = bs;
         HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
-        pl->slices_skipped++;
+        pl->slices_skipped += run;
+        *consumed = run;
         return FDES_OK;
     }
     // the pair's potential and both transmission functions are built at the pair's first non-empty slice:
@@ -412,7 +458,7 @@ int slice_loop(fdes_plan* pl, int nslices)
         const bool timing_probe = (oc->probe_stride > 0);
         if (!oc->opt_graph || timing_probe || nslices < 1) {
             RC(fused_enter(pl));
-            for (int s = 0; s < nslices; s++) RC(fused_slice(pl, s));
+            for (int s = 0, adv = 1; s < nslices; s += adv) RC(fused_slice(pl, s, nslices, &adv));
             return fused_leave(pl, nslices > 0);
         }
         // key: slice count, band option and the empty-slice pattern (FNV-1a over one bit per slice)
@@ -426,32 +472,41 @@ int slice_loop(fdes_plan* pl, int nslices)
         for (auto& e : pl->graphs) if (e.key == key) g = &e;
         if (!g) {
             const int64_t skipped0 = pl->slices_skipped;
+            std::vector<std::pair<int, float2*>> pow_owned;
+            pl->capture_pow = &pow_owned;
             pl->capturing = true;
             hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
             int rc = FDES_OK;
             if (e == hipSuccess) {
                 rc = fused_enter(pl);
-                for (int s = 0; s < nslices && rc == FDES_OK; s++) rc = fused_slice(pl, s);
+                for (int s = 0, adv = 1; s < nslices && rc == FDES_OK; s += adv) rc = fused_slice(pl, s, nslices, &adv);
                 if (rc == FDES_OK) rc = fused_leave(pl, true);
             }
             hipGraph_t graph = nullptr;
             hipError_t e2 = (e == hipSuccess) ? hipStreamEndCapture(c->stream, &graph) : e;
             pl->capturing = false;
+            pl->capture_pow = nullptr;
             const int64_t skipped = pl->slices_skipped - skipped0;
             pl->slices_skipped = skipped0;
-            if (rc != FDES_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            HIPCHK(c, e2);
             hipGraphExec_t exec = nullptr;
-            hipError_t e3 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            HIPCHK(c, e3);
+            hipError_t e3 = hipSuccess;
+            if (rc == FDES_OK && e2 == hipSuccess) e3 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc != FDES_OK || e2 != hipSuccess || e3 != hipSuccess) {
+                for (auto& e : pow_owned) (void)hipFree(e.second);
+                if (rc != FDES_OK) return rc;
+                HIPCHK(c, e2);
+                HIPCHK(c, e3);
+            }
             if (pl->graphs.size() >= 8) { // drop the least recently used pattern
                 size_t lru = 0;
                 for (size_t i = 1; i < pl->graphs.size(); i++) if (pl->graphs[i].used < pl->graphs[lru].used) lru = i;
+                (void)hipStreamSynchronize(c->stream); // a replay of the evicted graph may still be reading its tables
                 (void)hipGraphExecDestroy(pl->graphs[lru].exec);
+                for (auto& e : pl->graphs[lru].pow) (void)hipFree(e.second);
                 pl->graphs.erase(pl->graphs.begin() + (long)lru);
             }
-            pl->graphs.push_back({key, exec, skipped, 0});
+            pl->graphs.push_back({key, exec, skipped, 0, pow_owned});
             g = &pl->graphs.back();
         }
         g->used = ++pl->graph_tick;
@@ -617,7 +672,8 @@ int fdes_plan_destroy(fdes_plan* pl)
                     pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A == pl->C ? nullptr : pl->A, pl->C, pl->C2, pl->E, pl->PSIH,
                     pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT}; // F aliases C
     for (void* q : ptrs) if (q) (void)hipFree(q);
-    for (auto& g : pl->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : pl->graphs) { (void)hipGraphExecDestroy(g.exec); for (auto& e : g.pow) (void)hipFree(e.second); }
+    for (auto& e : pl->pow_tabs) if (e.tab) (void)hipFree(e.tab);
     for (auto& e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : pl->probe) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     fdes_params_release(&pl->p0);

@@ -32,6 +32,7 @@ hipError_t k_pick_potential(float2* V, const float2* W, size_t n, int comp, floa
 hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st);
 hipError_t k_mul(float2* dst, const float2* f0, const float2* f1, size_t n, hipStream_t st); // dst = f0 (x) f1, 3-mult
 hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_t st);
+hipError_t k_build_propagator_pow(float2* P, const KP& p, int transposed, int npow, hipStream_t st);
 hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, hipStream_t st);
 hipError_t k_lens(float2* psi, const KP& p, float defocus_k, hipStream_t st);
 hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre_scale, float alpha, hipStream_t st);

@@ -225,6 +225,34 @@ __global__ void kk_propagator(float2* __restrict__ P, KP p, int transposed)
     }
 }
 
+// n consecutive slices without atoms are n Fresnel steps: psi <- F^-1[P^n F[psi]].  P^n = alpha exp(i n phi) inside the
+// band (one FFT pair, so one alpha): phi is the FLOAT phase of kk_propagator (what the reference multiplies n times),
+// n phi and its sine / cosine are taken in double so that the run does not add rounding of its own.
+__global__ void kk_propagator_pow(float2* __restrict__ P, KP p, int transposed, int npow)
+{
+    const size_t n = (size_t)p.m1 * p.m2;
+    const float mindim = (float)(p.m1 < p.m2 ? p.m1 : p.m2);
+    const float alpha = 1.f / ((float)(p.m1 * p.m2));
+    GS_LOOP(i, n)
+    {
+        const int j1 = transposed ? (int)(i / (size_t)p.m2) : (int)(i % (size_t)p.m1);
+        const int j2 = transposed ? (int)(i % (size_t)p.m2) : (int)(i / (size_t)p.m1);
+        const int i1 = iw(j1, p.m1), i2 = iw(j2, p.m2);
+        float d3 = p.d3;
+        const float t1 = ((float)(i1) / ((float)p.m1)) * (d3 / p.d1);
+        const float t2 = ((float)(i2) / ((float)p.m2)) * (d3 / p.d2);
+        d3 = p.lambda / d3;
+        d3 = -PI_F * (t1 * t1 + t2 * t2) * d3;
+        double sn, cs;
+        sincos((double)d3 * (double)npow, &sn, &cs);
+        float2 v = make_float2((float)cs, (float)sn);
+        if (outside_band(i1, i2, mindim)) v = make_float2(0.f, 0.f);
+        v.x *= alpha;
+        v.y *= alpha;
+        P[i] = v;
+    }
+}
+
 // ---- multiplyLensFunction (src/multisliceSimulation.cu:277-343) --------------------------------
 __global__ void kk_lens(float2* __restrict__ psi, KP p, float defocus_k)
 {
@@ -478,6 +506,7 @@ hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st)
 }
 hipError_t k_mul(float2* dst, const float2* f0, const float2* f1, size_t n, hipStream_t st) { LAUNCH(kk_mul, n, st, dst, f0, f1, n); }
 hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_t st) { LAUNCH(kk_propagator, (size_t)p.m1 * p.m2, st, P, p, transposed); }
+hipError_t k_build_propagator_pow(float2* P, const KP& p, int transposed, int npow, hipStream_t st) { LAUNCH(kk_propagator_pow, (size_t)p.m1 * p.m2, st, P, p, transposed, npow); }
 hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, hipStream_t st) { LAUNCH(kk_gtab, (size_t)p.m1 * p.m2, st, G, p, kz, transposed); }
 hipError_t k_lens(float2* psi, const KP& p, float dk, hipStream_t st) { LAUNCH(kk_lens, (size_t)p.m1 * p.m2, st, psi, p, dk); }
 hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre, float alpha, hipStream_t st)

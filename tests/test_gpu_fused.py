@@ -78,17 +78,19 @@ def test_c1_reference_sized_case(engine, oracle):
 def test_empty_slice_fast_path(oracle):
     """Slices without atoms: with skip_empty the engine only applies the Fresnel step (t = 1 exactly); both settings
     must agree with the oracle, which always runs the full sequence."""
-    hp, at = S.case_tiny(m=256, m3=10, nz=2, nat=60, zfrac=0.18, frPh=2)
+    hp, at = S.case_tiny(m=256, m3=24, nz=2, nat=60, zfrac=0.12, frPh=2)
     fdes_amd.consistent(hp)
     ref = oracle.build_measurements(hp, at, prec="f64", want_exitwave=True)
     outs = {}
-    for skip in (0, 1):
+    for skip, graph in ((0, 1), (1, 1), (1, 0)):   # runs of empty slices become one step with P^n, with and without graphs
         eng = fdes_amd.Engine(0, skip_empty=skip)
-        outs[skip] = eng.build_measurements(hp, at, want_exitwave=True)
+        eng.set_option("graph", graph)
+        outs[(skip, graph)] = eng.build_measurements(hp, at, want_exitwave=True)
         eng.close()
-        check(outs[skip]["exitwave"], ref["exitwave"], None, 1e-5, f"exit wave, skip_empty={skip}")
-        check(outs[skip]["image"], ref["image"], None, 1e-5, f"image, skip_empty={skip}")
-    print("[parity] skip vs no-skip:", relerr(outs[1]["exitwave"], outs[0]["exitwave"].astype(np.float64)))
+        check(outs[(skip, graph)]["exitwave"], ref["exitwave"], None, 1e-5, f"exit wave, skip_empty={skip} graph={graph}")
+        check(outs[(skip, graph)]["image"], ref["image"], None, 1e-5, f"image, skip_empty={skip} graph={graph}")
+    print("[parity] skip vs no-skip:", relerr(outs[(1, 1)]["exitwave"], outs[(0, 1)]["exitwave"].astype(np.float64)))
+    assert np.array_equal(outs[(1, 1)]["image"], outs[(1, 0)]["image"])
 
 
 @pytest.mark.parametrize("m", [256, 1024])
