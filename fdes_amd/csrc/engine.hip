@@ -36,6 +36,7 @@ struct fdes_ctx {
     uint32_t seed = 1; // src/crystalMaker.cu:292
     bool is_lane_ctx = false;
     int bench_band = 0;   // fdes_bench_pass only
+    int bench_tall = 1;   // fdes_bench_pass only: rows = bench_tall * n (emulates a batch of configurations in one launch)
     float2* share_PT = nullptr; // lane contexts: tables owned by the parent plan
     float* share_GT = nullptr;
     int band_skip = 1;    // do not move / transform the rows and columns the 2/3 band limit zeroes anyway
@@ -649,6 +650,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
     if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "bench_tall")) { if (value < 1 || value > 4) return FDES_EINVAL; c->bench_tall = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_band")) { c->bench_band = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "skip_empty")) { c->skip_empty = value != 0; return FDES_OK; }
@@ -1172,7 +1174,7 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
     Fft2D f;
     std::string ferr;
     if (f.create(n, n, 2, c->stream, &ferr) != 0) { f.destroy(); c->err = ferr; return FDES_EGPU; }
-    const size_t m12 = (size_t)n * n;
+    const size_t m12 = (size_t)n * n * (size_t)c->bench_tall;
     std::vector<void*> bufs;
     std::vector<hipStream_t> sts;
     std::vector<PassArgs> args;
@@ -1189,7 +1191,7 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
         if (rc != FDES_OK) break;
         (void)hipMemset(a, 0, 8 * m12); (void)hipMemset(b, 0, 8 * m12); (void)hipMemset(pt, 0, 8 * m12); (void)hipMemset(g, 0, 4 * m12);
         PassArgs A;
-        A.in0 = a; A.in1 = b; A.out = o; A.zsrc = a; A.gtab = g; A.ptab = pt; A.tw0 = f.tw0x; A.tw1 = f.tw1x; A.nrows = n;
+        A.in0 = a; A.in1 = b; A.out = o; A.zsrc = a; A.gtab = g; A.ptab = pt; A.tw0 = f.tw0x; A.tw1 = f.tw1x; A.nrows = n * c->bench_tall;
         A.nspecies = 1; A.species_stride = m12; A.scale = 1.f; A.mindim = n;
         A.wg = c->pass_threads == 256 ? 256 : ((c->pass_threads == 513 || c->pass_threads == 1) && n <= 2048 ? 1 : 512);
         if (c->bench_band) { // micro-benchmark of the band-limit bookkeeping: bit 0 live rows only, bit 1 dead loads, bit 2 dead stores
