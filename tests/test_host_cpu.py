@@ -462,3 +462,28 @@ def test_cfg_reader_partial_occupancy_is_refused(tmp_path):
     with pytest.raises(fdes_amd.FdesError) as e:
         fdes_amd.read_qsc(p)
     assert e.value.code == -5
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """include/fdes_abi.h compiles as C99 and as C++17, and a C program linked against libFDES_SHARED_LIB.so reads the
+    reference's Au-309 .cnf through the C-ABI (no Python, no GPU)."""
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "fdes_amd", "csrc")
+    src = os.path.join(ROOT, "tests", "abi_c", "host_check.c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, src])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-fsyntax-only", "-x", "c++", "-I", inc, src])
+    exe = str(tmp_path / "host_check")
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, src, "-o", exe, "-L", libdir, "-lFDES_SHARED_LIB",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    cnf = tmp_path / "au.cnf"
+    hp, at = fdes_amd.read_emd(EMD_FIXTURE) if fdes_amd.emd_available() else (None, None)
+    if hp is None:
+        hp, at = S.case_tiny(m=64, m3=4, nz=2)
+        fdes_amd.consistent(hp)
+    fdes_amd.write_cnf(cnf, hp, at)
+    out = subprocess.run([exe, str(cnf)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    kv = dict(t.split("=") for t in out.stdout.split())
+    # the bug-compatible reader duplicates the last atom when the file ends in a newline (SURVEY 8f-2)
+    assert int(kv["nAt"]) in (at.n, at.n + 1) and int(kv["m1"]) == hp.c.m1 and int(kv["m3_sub"]) >= int(kv["m3"])
+    assert abs(float(kv["lambda"]) / hp.c.lambda_ - 1) < 1e-6
