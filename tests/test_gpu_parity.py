@@ -423,3 +423,23 @@ def test_shipped_si001_example_through_the_cli(oracle, tmp_path):
     print("[parity] Si[001] 11k CLI (1000^2 x 205 slices): E(gpu vs cpu_f32) =", e, "contrast", ref.std() / ref.mean())
     assert ref.std() / ref.mean() > 1e-2
     assert e < 5e-5
+
+
+def test_c_host_program_runs_a_simulation(engine, tmp_path):
+    """The C-ABI without Python in the compute path: tests/abi_c/host_check.c (plain C99) reads a .cnf, calls
+    fdes_build_measurements and writes the image stack; the result equals the same call through the ctypes binding."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(G), ".."))
+    libdir = os.path.join(root, "fdes_amd", "csrc")
+    exe = str(tmp_path / "host_check")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "abi_c", "host_check.c"),
+                           "-o", exe, "-L", libdir, "-lFDES_SHARED_LIB", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    hp, at = S.case_tiny(m=256, m3=6, nz=2, frPh=2, n3=2, tilt=True)
+    fdes_amd.consistent(hp)
+    fdes_amd.write_cnf(tmp_path / "case.cnf", hp, at)
+    r = subprocess.run([exe, str(tmp_path / "case.cnf"), str(tmp_path / "image.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    hq, aq = fdes_amd.read_cnf(tmp_path / "case.cnf")
+    ref = engine.build_measurements(hq, aq)["image"]
+    img = np.fromfile(tmp_path / "image.bin", np.float32).reshape(ref.shape)
+    assert np.array_equal(img, ref)
