@@ -36,6 +36,7 @@ struct fdes_ctx {
     uint32_t seed = 1; // src/crystalMaker.cu:292
     bool is_lane_ctx = false;
     int bench_band = 0;   // fdes_bench_pass only
+    int bench_alt = -1;   // fdes_bench_pass only: >= 0: odd streams run pass (alt / 10000, alt / 100 % 100, alt % 100) instead
     int bench_tall = 1;   // fdes_bench_pass only: rows = bench_tall * n (emulates a batch of configurations in one launch)
     float2* share_PT = nullptr; // lane contexts: tables owned by the parent plan
     float* share_GT = nullptr;
@@ -650,6 +651,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
     if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "bench_alt")) { c->bench_alt = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_tall")) { if (value < 1 || value > 4) return FDES_EINVAL; c->bench_tall = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_band")) { c->bench_band = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
@@ -1204,11 +1206,15 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
     }
     if (rc == FDES_OK) {
         hipError_t e = hipSuccess;
-        for (int q = 0; q < streams && e == hipSuccess; q++) e = lds_pass(n, pre, mid, post, store_t != 0, args[q], sts[q]);
+        auto go = [&](int q) {
+            if (c->bench_alt >= 0 && (q & 1)) return lds_pass(n, c->bench_alt / 10000, c->bench_alt / 100 % 100, c->bench_alt % 100, store_t != 0, args[q], sts[q]);
+            return lds_pass(n, pre, mid, post, store_t != 0, args[q], sts[q]);
+        };
+        for (int q = 0; q < streams && e == hipSuccess; q++) e = go(q);
         (void)hipDeviceSynchronize();
         auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < iters && e == hipSuccess; i++)
-            for (int q = 0; q < streams && e == hipSuccess; q++) e = lds_pass(n, pre, mid, post, store_t != 0, args[q], sts[q]);
+            for (int q = 0; q < streams && e == hipSuccess; q++) e = go(q);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         auto t1 = std::chrono::steady_clock::now();
         if (e == hipSuccess) *us = std::chrono::duration<double, std::micro>(t1 - t0).count() / ((double)iters * streams);
