@@ -5,5 +5,5 @@ this package is its ctypes host binding.  Nothing here computes: if the library 
 entry point raises.
 """
 from .abi import HostAtoms, HostParams, load_library  # noqa: F401
-from .api import (Engine, FdesError, Plan, consistent, emd_available, gpu_available, read_cnf, read_emd, read_qsc, run_file,  # noqa: F401
+from .api import (Engine, FdesError, Plan, build_measurements_multi, consistent, emd_available, gpu_available, read_cnf, read_emd, read_qsc, run_file,  # noqa: F401
                   sub_sliced, write_cnf, write_emd)

@@ -145,6 +145,7 @@ PROTOTYPES = [
                                  _P(C.c_float), C.c_int]),
     ("fdes_read_emd", C.c_int, [C.c_char_p, _P(Params), _P(Atoms), C.c_int]),
     ("fdes_read_qsc", C.c_int, [C.c_char_p, _P(Params), _P(Atoms), C.c_int]),
+    ("fdes_build_measurements_multi", C.c_int, [C.c_int, _P(C.c_int), _P(Params), _P(Atoms), _P(C.c_float)]),
     ("fdes_emd_available", C.c_int, []),
     ("fdes_create", C.c_int, [_P(_vp), C.c_int]),
     ("fdes_destroy", C.c_int, [_vp]),

@@ -63,6 +63,15 @@ def read_emd(path, skip_atoms=False, capacity=1000):
     return _read_file(path, "fdes_read_emd", 2 if skip_atoms else 0, skip_atoms, capacity)
 
 
+def build_measurements_multi(devices, hp, atoms):
+    """fdes_build_measurements_multi: one host thread per entry of `devices`; returns image[n3, n2, n1]."""
+    lib = abi.load_library()
+    dev = (C.c_int * len(devices))(*devices)
+    img = np.zeros((hp.c.n3, hp.c.n2, hp.c.n1), np.float32)
+    _chk(lib.fdes_build_measurements_multi(len(devices), dev, hp.ptr, atoms.ptr, fptr(img)))
+    return img
+
+
 def read_qsc(path, skip_atoms=False, capacity=1000):
     """readQsc (src/rwQsc.cu:8-1101): QSTEM .qsc + the .cfg cell it names -> (HostParams, HostAtoms or None)."""
     return _read_file(path, "fdes_read_qsc", 2 if skip_atoms else 0, skip_atoms, capacity)

@@ -115,6 +115,11 @@ struct fdes_plan {
 namespace {
 
 std::once_flag g_rocfft_once;
+// Host threads driving different GPUs (or several plans on one GPU) share the process: a stream capture in one thread is
+// invalidated by synchronising runtime calls (hipMalloc, hipFree, blocking hipMemcpy) made by another thread meanwhile
+// ("operation failed due to a previous error during capture").  Captures are rare (once per empty-slice pattern) and
+// those calls only occur in plan creation / destruction, so the two are simply serialised.
+std::recursive_mutex g_capture_mutex;
 
 #define HIPCHK(ctx, expr)                                                                         \
     do {                                                                                          \
@@ -319,6 +324,7 @@ int propagator_pow(fdes_plan* pl, int n, float2** out)
     }
     for (auto& e : pl->pow_tabs)
         if (e.n == n) { e.used = ++pl->pow_tick; *out = e.tab; return FDES_OK; }
+    std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc
     float2* tab = nullptr;
     if (pl->pow_tabs.size() >= 6) {
         size_t lru = 0;
@@ -473,6 +479,7 @@ int slice_loop(fdes_plan* pl, int nslices)
         fdes_plan::LoopGraph* g = nullptr;
         for (auto& e : pl->graphs) if (e.key == key) g = &e;
         if (!g) {
+            std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
             const int64_t skipped0 = pl->slices_skipped;
             std::vector<std::pair<int, float2*>> pow_owned;
             pl->capture_pow = &pow_owned;
@@ -664,6 +671,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
 int fdes_plan_destroy(fdes_plan* pl)
 {
     if (!pl) return FDES_EINVAL;
+    std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
     fdes_ctx* c = pl->ctx;
     (void)hipSetDevice(c->device);
     for (fdes_plan* l : pl->lanes) fdes_plan_destroy(l);
@@ -689,6 +697,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
 {
     if (!c || !out) return FDES_EINVAL;
     *out = nullptr;
+    std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
     RC(check_params(c, p_in, a));
     HIPCHK(c, hipSetDevice(c->device));
     fdes_plan* pl = new fdes_plan();
@@ -944,8 +953,9 @@ int fdes_plan_copy_intensity(fdes_plan* pl, void* dev_buf, int to_plan)
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     RC(fold_lanes(pl));
-    if (to_plan) HIPCHK(c, hipMemcpyAsync(pl->I, dev_buf, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
-    else HIPCHK(c, hipMemcpyAsync(dev_buf, pl->I, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
+    // hipMemcpyDefault: `dev_buf` may be device memory (RCCL buffers of the one-process-per-GPU launch) or host memory
+    if (to_plan) HIPCHK(c, hipMemcpyAsync(pl->I, dev_buf, sizeof(float2) * pl->m12, hipMemcpyDefault, c->stream));
+    else HIPCHK(c, hipMemcpyAsync(dev_buf, pl->I, sizeof(float2) * pl->m12, hipMemcpyDefault, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FDES_OK;
 }

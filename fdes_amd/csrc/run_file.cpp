@@ -52,6 +52,26 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     }
     std::vector<float> image, potential, exitwave;
     fdes_ctx* ctx = nullptr;
+    // Extension: FDES_DEVICES="0,1,2,3" (or FDES_NUM_GPUS=n: devices gpu_index ... gpu_index + n - 1) spreads the
+    // (measurement, phonon configuration) pairs over several GPUs; print_level 0 only (images).
+    std::vector<int> devices;
+    if (const char* e = std::getenv("FDES_DEVICES")) {
+        for (const char* q = e; *q;) {
+            char* end = nullptr;
+            long v = std::strtol(q, &end, 10);
+            if (end == q) break;
+            devices.push_back((int)v);
+            q = (*end == ',') ? end + 1 : end;
+        }
+    } else if (const char* e = std::getenv("FDES_NUM_GPUS")) {
+        for (int i = 0; i < std::atoi(e); i++) devices.push_back(gpu_index + i);
+    }
+    if (rc == FDES_OK && devices.size() > 1 && print_level == 0) {
+        image.resize((size_t)p0.n1 * p0.n2 * p0.n3);
+        std::fprintf(stderr, "  FDES: %zu GPUs\n", devices.size());
+        rc = fdes_build_measurements_multi((int)devices.size(), devices.data(), &p0, &atoms, image.data());
+        if (rc) std::fprintf(stderr, "  FDES: multi-GPU simulation failed (%d)\n", rc);
+    } else {
     if (rc == FDES_OK) {
         rc = fdes_create(&ctx, gpu_index);
         if (rc) std::fprintf(stderr, "  FDES: no usable GPU with index %d\n", gpu_index);
@@ -64,6 +84,7 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
         rc = fdes_build_measurements(ctx, &p0, &atoms, image.data(), print_level > 0 ? potential.data() : nullptr,
                                      print_level > 1 ? exitwave.data() : nullptr);
         if (rc) std::fprintf(stderr, "  FDES: simulation failed: %s\n", fdes_last_error(ctx));
+    }
     }
     if (rc == FDES_OK) {
         if (image_name) rc = fdes_write_binary(image_name, image.data(), image.size()); // src/crystalMaker.cu:399

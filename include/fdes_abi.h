@@ -135,6 +135,12 @@ int fdes_gpu_available(void);
 int fdes_build_measurements(fdes_ctx* ctx, const fdes_params* p, const fdes_atoms* atoms,
                             float* image, float* potential, float* exitwave);
 
+/* The same over `ngpu` GPUs of one node from one host process (one host thread per device in `devices`): the (k, j)
+ * configurations of src/crystalMaker.cu:324-367 are block-partitioned over the GPUs, partial intensity sums of a
+ * measurement that spans GPUs are added in ascending order of the list, its first GPU applies addNoiseAndMtf.  Images
+ * only (the potential / exit-wave outputs of print_level > 0 stay on the single-GPU call). */
+int fdes_build_measurements_multi(int ngpu, const int* devices, const fdes_params* p, const fdes_atoms* atoms, float* image);
+
 /* ---- resident interface: the same loops, split so that inputs stay in HBM and the
  * (k, j) configurations can be sharded over GPUs (src/crystalMaker.cu:324-373) ---- */
 

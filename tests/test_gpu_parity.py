@@ -443,3 +443,26 @@ def test_c_host_program_runs_a_simulation(engine, tmp_path):
     ref = engine.build_measurements(hq, aq)["image"]
     img = np.fromfile(tmp_path / "image.bin", np.float32).reshape(ref.shape)
     assert np.array_equal(img, ref)
+
+
+def test_multi_gpu_driver_in_one_process(engine, tmp_path):
+    """fdes_build_measurements_multi (C++ host threads, one per device): three 'GPUs' that are all device 0 must give
+    the single-GPU images up to the association order of the per-measurement intensity sum; also through the CLI
+    (FDES_DEVICES)."""
+    import subprocess
+    hp, at = S.case_tiny(m=256, m3=6, nz=2, frPh=4, n3=3, tilt=True, pD=0.0)
+    fdes_amd.consistent(hp)
+    ref = engine.build_measurements(hp, at)["image"]
+    for devs in ([0, 0], [0, 0, 0], [0, 0, 0, 0, 0]):
+        out = fdes_amd.build_measurements_multi(devs, hp, at)
+        e = relerr(out, ref)
+        print(f"[parity] multi-GPU driver with {len(devs)} workers vs single: {e:.3e}")
+        assert e < 2e-6 and np.isfinite(out).all()
+    fdes_amd.write_cnf(tmp_path / "case.cnf", hp, at)
+    exe = os.path.abspath(os.path.join(os.path.dirname(G), "..", "fdes_amd", "csrc", "FDES"))
+    env = dict(os.environ, FDES_DEVICES="0,0,0", FDES_STRICT_CNF="1")
+    r = subprocess.run([exe, "--input_name", "case.cnf", "--image_name", "m.bin", "--emd_name", "r.emd"], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "3 GPUs" in r.stderr, r.stderr[-1500:]
+    img = np.fromfile(tmp_path / "m.bin", np.float32).reshape(ref.shape)
+    assert relerr(img, ref) < 2e-6
