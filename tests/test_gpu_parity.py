@@ -466,3 +466,23 @@ def test_multi_gpu_driver_in_one_process(engine, tmp_path):
     assert r.returncode == 0 and "3 GPUs" in r.stderr, r.stderr[-1500:]
     img = np.fromfile(tmp_path / "m.bin", np.float32).reshape(ref.shape)
     assert relerr(img, ref) < 2e-6
+
+
+@pytest.mark.parametrize("seed", list(range(14)))
+def test_randomised_parameter_sweep(engine, oracle, seed):
+    """Random draws over the parameter surface (mode, grid size / path, species, sub-slicing, odd and even slice counts,
+    empty slices, specimen and beam tilts, several measurements, frozen phonons, rectangular grids): images against the
+    float64 oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    fused = bool(rng.integers(0, 2))
+    rect = bool(rng.integers(0, 4) == 0)
+    kw = dict(m=int(rng.choice([256, 512])) if fused else int(rng.choice([48, 64, 96])),
+              m3=int(rng.integers(1, 8)), nz=int(rng.integers(1, 4)), frPh=int(rng.choice([0, 0, 2, 3])),
+              mode=int(rng.choice([0, 0, 1, 2])), n3=int(rng.integers(1, 3)), seed=int(rng.integers(0, 1000)),
+              tilt=bool(rng.integers(0, 2)), beam_tilt=bool(rng.integers(0, 2)), imPot=float(rng.choice([0.0, 0.05, 0.2])),
+              rect=rect, nat=int(rng.integers(1, 120)), sub=int(rng.integers(1, 4)), zfrac=float(rng.choice([0.5, 0.3, 0.15])))
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
+    out = engine.build_measurements(hp, at)["image"]
+    ref = oracle.build_measurements(hp, at, prec="f64")["image"]
+    check(out, ref, None, 2e-5, f"sweep {seed}: {kw}")
