@@ -487,3 +487,24 @@ def test_c_abi_from_plain_c(tmp_path):
     # the bug-compatible reader duplicates the last atom when the file ends in a newline
     assert int(kv["nAt"]) in (at.n, at.n + 1) and int(kv["m1"]) == hp.c.m1 and int(kv["m3_sub"]) >= int(kv["m3"])
     assert abs(float(kv["lambda"]) / hp.c.lambda_ - 1) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["dataFDES_bin.cnf", "dataFDES_Auparticle.cnf"])
+def test_shipped_cnf_files_parse(name):
+    """The reference's own .cnf inputs (bin/dataFDES.cnf, ExampleSpecimens/Au_cubeoctahedron_cnf): 309 Au atoms, 25
+    measurements, 320^2 wave; the bug-compatible reader reproduces getParams' duplicated last atom when the file ends
+    in a newline, the clean reader does not; against the shipped Auparticle.emd they describe the same simulation."""
+    path = os.path.join(ROOT, "tests", "golden", name)
+    hp, at = fdes_amd.read_cnf(path, bug_compatible=False)
+    hb, ab = fdes_amd.read_cnf(path, bug_compatible=True)
+    c = hp.c
+    assert at.n == 309 and ab.n in (309, 310) and np.all(at.Z == 79)
+    assert (c.m1, c.m2, c.m3, c.n1, c.n2, c.n3, c.dn1) == (320, 320, 12, 160, 160, 25, 80)
+    assert np.array_equal(ab.xyz[:309], at.xyz) and (ab.n == 309 or np.array_equal(ab.xyz[309], at.xyz[308]))
+    q, ratio = fdes_amd.sub_sliced(hp)
+    assert ratio == 11 and q.c.m3 == 132                      # 2.1 A slices cut to ~0.2 A (SURVEY 8a2)
+    if fdes_amd.emd_available():
+        he, ae = fdes_amd.read_emd(EMD_FIXTURE)
+        assert ae.n == 309 and (he.c.m1, he.c.m3, he.c.n3) == (c.m1, c.m3, c.n3)
+        assert np.allclose(ae.xyz, at.xyz, rtol=0, atol=1e-16) and abs(he.c.pD - c.pD) < 1e-6
+        assert np.allclose(he.tiltspec[:50], hp.tiltspec[:50], atol=1e-7)
