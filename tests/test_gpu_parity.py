@@ -486,3 +486,24 @@ def test_randomised_parameter_sweep(engine, oracle, seed):
     out = engine.build_measurements(hp, at)["image"]
     ref = oracle.build_measurements(hp, at, prec="f64")["image"]
     check(out, ref, None, 2e-5, f"sweep {seed}: {kw}")
+
+
+def test_shipped_qsc_example_through_the_cli(oracle, tmp_path):
+    """The reference's bin/test.qsc as shipped: SrTiO3 9x9x20 cells (8 100 atoms, three species), nx = 400 -> 800^2 wave
+    (rocFFT path), 40 slices cut into 400 sub-slices, CBED probe (cal_mode 2), pixel dose 10 -> Poisson surrogate noise;
+    FDES CLI against the float32 oracle with the same Philox streams."""
+    import subprocess
+    src = os.path.join(G, "qsc", "test.qsc")
+    exe = os.path.abspath(os.path.join(os.path.dirname(G), "..", "fdes_amd", "csrc", "FDES"))
+    r = subprocess.run([exe, "--input_name", src, "--image_name", "Measurements.bin", "--emd_name", "results.emd"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    hp, at = fdes_amd.read_qsc(src)
+    assert (hp.c.m1, hp.c.m3, hp.c.mode, at.n) == (800, 40, 2, 8100)
+    img = np.fromfile(tmp_path / "Measurements.bin", np.float32).reshape(1, 400, 400)
+    ref = oracle.build_measurements(hp, at, prec="f32")["image"]
+    close = np.abs(img - ref) < 1e-4 * ref.max()
+    print("[parity] test.qsc CLI (800^2, 400 sub-slices, CBED, dose 10): fraction of pixels equal to rounding:", close.mean(),
+          "mean", img.mean(), ref.mean())
+    assert close.mean() > 0.97
+    assert abs(img.mean() - ref.mean()) < 2e-3 * abs(ref.mean())
