@@ -843,7 +843,8 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     // the kernels are no longer than that gap (each lane on a stream of its own priority class, see create_ctx), two
     // above (a third lane only thrashes the Infinity Cache at 2048^2; equal priorities there: a high-priority lane
     // starves the other one of workgroup slots, -1.5 %).
-    const int nlanes = c->lanes > 0 ? c->lanes : (pl->m12 <= (size_t)1024 * 1024 ? 3 : 2);
+    // (the rocFFT path stays at two: with three prioritised lanes it drops from 9.2 k to 3.6 k slices/s at 800^2)
+    const int nlanes = c->lanes > 0 ? c->lanes : ((pl->fused && pl->m12 <= (size_t)1024 * 1024) ? 3 : 2);
     if (nlanes > 1 && !c->is_lane_ctx) {
         for (int l = 1; l < nlanes; l++) {
             fdes_ctx* lc = nullptr;
