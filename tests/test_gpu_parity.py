@@ -507,3 +507,26 @@ def test_shipped_qsc_example_through_the_cli(oracle, tmp_path):
           "mean", img.mean(), ref.mean())
     assert close.mean() > 0.97
     assert abs(img.mean() - ref.mean()) < 2e-3 * abs(ref.mean())
+
+
+def test_c3_headline_size_single_configuration(oracle):
+    """The headline workload itself (C3: Au cuboctahedron, 94 611 atoms, 2048^2 wave, 256 slices; one configuration,
+    frozen phonons off so that the float64 oracle is the truth): SURVEY 8c's acceptance rule E(gpu) <= 2 E(cpu_f32) and
+    E(gpu) <= 1e-4, for the full sequence on every slice and for the engine default (runs of empty slices as one
+    Fresnel step with P^n)."""
+    hp, at = S.case_c3(frPh=0)
+    fdes_amd.consistent(hp)
+    outs = {}
+    for skip in (0, 1):
+        eng = fdes_amd.Engine(0, skip_empty=skip)
+        outs[skip] = eng.build_measurements(hp, at)["image"]
+        eng.close()
+    r32 = oracle.build_measurements(hp, at, prec="f32")["image"]
+    r64 = oracle.build_measurements(hp, at, prec="f64")["image"]
+    e32 = relerr(r32, r64)
+    for skip in (0, 1):
+        e = relerr(outs[skip], r64)
+        print(f"[parity] C3 2048^2 x 256 slices, skip_empty={skip}: E(gpu)={e:.3e} E(cpu_f32)={e32:.3e}")
+        assert e <= 2 * e32 and e <= 1e-4
+        assert np.abs(outs[skip] - r64).max() <= 1e-3 * np.abs(r64).max()
+    assert r64.std() / r64.mean() > 0.05
