@@ -128,6 +128,9 @@ class HostAtoms:
         return a
 
 
+# fdes_progress_fn: void (*)(void* user, int64_t done, int64_t total)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
+
 # (name, restype, argtypes) of every symbol include/fdes_abi.h declares
 _P = C.POINTER
 _vp = C.c_void_p
@@ -145,7 +148,13 @@ PROTOTYPES = [
                                  _P(C.c_float), C.c_int]),
     ("fdes_read_emd", C.c_int, [C.c_char_p, _P(Params), _P(Atoms), C.c_int]),
     ("fdes_read_qsc", C.c_int, [C.c_char_p, _P(Params), _P(Atoms), C.c_int]),
-    ("fdes_build_measurements_multi", C.c_int, [C.c_int, _P(C.c_int), _P(Params), _P(Atoms), _P(C.c_float)]),
+    ("fdes_build_measurements_multi", C.c_int, [C.c_int, _P(C.c_int), _P(Params), _P(Atoms), _P(C.c_float), _P(C.c_float),
+                                                _P(C.c_float)]),
+    ("fdes_plan_accumulate_from", C.c_int, [_vp, _vp]),
+    ("fdes_plan_want_exitwave", C.c_int, [_vp, C.c_int]),
+    ("fdes_plan_get_exitwave", C.c_int, [_vp, _P(C.c_float)]),
+    ("fdes_plan_potential", C.c_int, [_vp, C.c_int, C.c_int, _P(C.c_float)]),
+    ("fdes_plan_original_slices", C.c_int, [_vp]),
     ("fdes_emd_available", C.c_int, []),
     ("fdes_create", C.c_int, [_P(_vp), C.c_int]),
     ("fdes_destroy", C.c_int, [_vp]),
@@ -177,6 +186,7 @@ PROTOTYPES = [
     ("fdes_fft2d_host", C.c_int, [_vp, _P(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int]),
     ("fdes_bench_pass", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P(C.c_double)]),
     ("fdes_set_option", C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    ("fdes_set_progress", C.c_int, [_vp, _vp, _vp, C.c_int]),
     ("FDES", None, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, _P(C.c_float), C.c_int,
                     _P(C.c_float)]),
     ("fdes_run_file", C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, _P(C.c_float),

@@ -63,13 +63,20 @@ def read_emd(path, skip_atoms=False, capacity=1000):
     return _read_file(path, "fdes_read_emd", 2 if skip_atoms else 0, skip_atoms, capacity)
 
 
-def build_measurements_multi(devices, hp, atoms):
-    """fdes_build_measurements_multi: one host thread per entry of `devices`; returns image[n3, n2, n1]."""
+def build_measurements_multi(devices, hp, atoms, want_potential=False, want_exitwave=False):
+    """fdes_build_measurements_multi: one host thread per entry of `devices`.  Returns image[n3, n2, n1], or the same
+    dict as Engine.build_measurements when a potential / exit-wave output is asked for."""
     lib = abi.load_library()
     dev = (C.c_int * len(devices))(*devices)
-    img = np.zeros((hp.c.n3, hp.c.n2, hp.c.n1), np.float32)
-    _chk(lib.fdes_build_measurements_multi(len(devices), dev, hp.ptr, atoms.ptr, fptr(img)))
-    return img
+    c = hp.c
+    img = np.zeros((c.n3, c.n2, c.n1), np.float32)
+    pot = np.zeros((c.m3, c.m2, c.m1, 2), np.float32) if want_potential else None
+    ew = np.zeros((c.n3, c.m2, c.m1, 2), np.float32) if want_exitwave else None
+    _chk(lib.fdes_build_measurements_multi(len(devices), dev, hp.ptr, atoms.ptr, fptr(img), fptr(pot) if want_potential else None,
+                                           fptr(ew) if want_exitwave else None))
+    if not (want_potential or want_exitwave):
+        return img
+    return {"image": img, "potential": pot, "exitwave": ew}
 
 
 def read_qsc(path, skip_atoms=False, capacity=1000):
@@ -150,6 +157,12 @@ class Engine:
 
     def set_option(self, key, value):
         _chk(self.lib.fdes_set_option(self.h, key.encode(), int(value)), key)
+
+    def set_progress(self, fn, min_interval_ms=200):
+        """fn(done, total) in slice-propagations, called between configurations of build_measurements; None removes it."""
+        self._progress_cb = abi.PROGRESS_FN(lambda _u, d, t: fn(int(d), int(t))) if fn else None  # keep the thunk alive
+        _chk(self.lib.fdes_set_progress(self.h, C.cast(self._progress_cb, C.c_void_p) if fn else None, None,
+                                        int(min_interval_ms)))
 
     def err(self):
         return (self.lib.fdes_last_error(self.h) or b"").decode()
@@ -266,6 +279,18 @@ class Plan:
         t, n = C.c_double(), C.c_int64()
         self._c(self.lib.fdes_plan_probe_ms(self.h, C.byref(t), C.byref(n)))
         return t.value, n.value
+
+    def accumulate_from(self, other):
+        """I (and the exit-wave sum) += other's, device to device (fdes_plan_accumulate_from)."""
+        self._c(self.lib.fdes_plan_accumulate_from(self.h, other.h))
+
+    def want_exitwave(self, on=True):
+        self._c(self.lib.fdes_plan_want_exitwave(self.h, int(on)))
+
+    def get_exitwave(self):
+        out = np.zeros((self.m2, self.m1, 2), np.float32)
+        self._c(self.lib.fdes_plan_get_exitwave(self.h, fptr(out)))
+        return out[..., 0] + 1j * out[..., 1]
 
     def fft_backend(self):
         return int(self.lib.fdes_plan_fft_backend(self.h))

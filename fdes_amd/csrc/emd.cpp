@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -62,12 +63,17 @@ struct H5 {
     hid_t T_FLOAT = -1, T_INT = -1, T_UCHAR = -1, T_C_S1 = -1;
 };
 
+void h5_load(H5& h);
+// the library is looked for once per process; concurrent first callers (one host thread per GPU) wait for the loader
 H5& h5()
 {
     static H5 h;
-    static bool tried = false;
-    if (tried) return h;
-    tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] { h5_load(h); });
+    return h;
+}
+void h5_load(H5& h)
+{
     std::vector<std::string> names;
     if (const char* e = std::getenv("FDES_HDF5_LIB")) names.push_back(e);
     for (const char* n : {"libhdf5.so", "libhdf5.so.103", "libhdf5.so.200", "libhdf5_serial.so", "libhdf5_serial.so.103",
@@ -77,7 +83,7 @@ H5& h5()
         h.so = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (h.so) break;
     }
-    if (!h.so) return h;
+    if (!h.so) return;
     bool all = true;
 #define SYM(field, name) *(void**)(&h.field) = dlsym(h.so, name); if (!h.field) all = false;
     SYM(open, "H5open") SYM(get_libversion, "H5get_libversion") SYM(Fcreate, "H5Fcreate") SYM(Fopen, "H5Fopen") SYM(Fclose, "H5Fclose")
@@ -89,10 +95,10 @@ H5& h5()
     SYM(Tcopy, "H5Tcopy") SYM(Tset_size, "H5Tset_size") SYM(Tset_strpad, "H5Tset_strpad") SYM(Tget_size, "H5Tget_size") SYM(Tclose, "H5Tclose")
     SYM(Lexists, "H5Lexists") SYM(Eset_auto2, "H5Eset_auto2")
 #undef SYM
-    if (!all) return h;
+    if (!all) return;
     unsigned maj = 0, min = 0, rel = 0;
-    if (h.get_libversion(&maj, &min, &rel) < 0 || maj != 1 || min < 10) return h; // hid_t is 64-bit from 1.10 on
-    if (h.open() < 0) return h;
+    if (h.get_libversion(&maj, &min, &rel) < 0 || maj != 1 || min < 10) return; // hid_t is 64-bit from 1.10 on
+    if (h.open() < 0) return;
     auto glob = [&](const char* n) -> hid_t { hid_t* p = (hid_t*)dlsym(h.so, n); return p ? *p : -1; };
     h.T_FLOAT = glob("H5T_NATIVE_FLOAT_g");
     h.T_INT = glob("H5T_NATIVE_INT_g");
@@ -100,7 +106,7 @@ H5& h5()
     h.T_C_S1 = glob("H5T_C_S1_g");
     h.ok = h.T_FLOAT >= 0 && h.T_INT >= 0 && h.T_UCHAR >= 0 && h.T_C_S1 >= 0;
     if (h.ok) h.Eset_auto2(0, nullptr, nullptr); // no HDF5 error stack printing: errors are return codes here
-    return h;
+    return;
 }
 
 // ---- attribute helpers: scalars are rank-1 [1] arrays (rwHdf5.cu:2591-2604), strings are fixed-size = strlen,

@@ -14,9 +14,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "fdes_internal.h"
@@ -46,7 +49,19 @@ struct fdes_ctx {
     int lanes = 0;        // configurations in flight at once (own stream + buffers each) in the fused slice loop; 0: by grid size
     int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
-    std::map<std::pair<int, int>, Fft2D*> fft_cache; // plans are expensive to create: one per grid size
+    // plans are expensive to create: one per grid size AND requested back-end (option "fft" may change between plans)
+    std::map<std::tuple<int, int, int>, Fft2D*> fft_cache;
+    // plans created on this context and not yet destroyed: fdes_destroy takes them down first, so a host that forgets
+    // fdes_plan_destroy (or a Python finaliser that runs late) cannot leave a plan pointing at a dead context
+    std::vector<fdes_plan*> plans;
+    // progress report (the reference prints a percentage from inside its slice loop, src/crystalMaker.cu:341 ->
+    // src/optimFunctions.cu:257): called on the host between configurations, never from a captured graph
+    fdes_progress_fn progress = nullptr;
+    void* progress_user = nullptr;
+    int progress_min_ms = 200;
+    std::chrono::steady_clock::time_point progress_last{};
+    int64_t progress_total = 0; // slice-propagations of the whole job (0: unknown)
+    int64_t progress_done = 0;
 };
 
 struct EvPair { hipEvent_t a, b; int slices; };
@@ -97,7 +112,7 @@ struct fdes_plan {
     uint64_t pow_tick = 0;
     // hipGraph replay of the fused slice loop (option "graph"): the launch sequence of a configuration depends only on
     // the number of slices and on which slices are empty, so an instantiated graph is kept per such pattern
-    struct LoopGraph { uint64_t key; hipGraphExec_t exec; int64_t skipped; uint64_t used; std::vector<std::pair<int, float2*>> pow; };
+    struct LoopGraph { uint64_t key; std::vector<uint8_t> pattern; hipGraphExec_t exec; int64_t skipped; uint64_t used; std::vector<std::pair<int, float2*>> pow; };
     std::vector<std::pair<int, float2*>>* capture_pow = nullptr; // P^n tables of the graph being captured (built by its own nodes)
     std::vector<LoopGraph> graphs;
     uint64_t graph_tick = 0;
@@ -106,9 +121,12 @@ struct fdes_plan {
     size_t probe_used = 0;
     uint64_t fft_calls = 0;
     bool want_ew = false;
+    float2* peer_stage = nullptr;   // landing buffer for another GPU's partial sum (fdes_plan_accumulate_from)
+    hipEvent_t peer_ev = nullptr;
     // timing
     std::vector<EvPair> evs;
     size_t ev_used = 0;
+    size_t ev_done = 0; // events of one stream complete in order: evs[i].b has been seen complete for i < ev_done
     int64_t slices_done = 0;
 };
 
@@ -120,6 +138,20 @@ std::once_flag g_rocfft_once;
 // ("operation failed due to a previous error during capture").  Captures are rare (once per empty-slice pattern) and
 // those calls only occur in plan creation / destruction, so the two are simply serialised.
 std::recursive_mutex g_capture_mutex;
+
+// Live handles.  Every entry point that destroys checks its handle here first, so destroying twice, destroying a plan
+// after its context, or a finaliser that runs after the at-exit sweep below are refused (FDES_EINVAL) instead of
+// touching freed memory.
+std::mutex g_live_mutex;
+std::set<const void*> g_live_ctx, g_live_plan;
+bool live_ctx(const fdes_ctx* c) { std::lock_guard<std::mutex> g(g_live_mutex); return g_live_ctx.count(c) != 0; }
+bool live_plan(const fdes_plan* p) { std::lock_guard<std::mutex> g(g_live_mutex); return g_live_plan.count(p) != 0; }
+std::once_flag g_atexit_once;
+void shutdown_all();
+
+// run-time options of a lane are those of the context that owns the plan (the lane contexts are private copies made at
+// plan creation: only what shapes the allocation - fft, lanes, pass_threads - is frozen there)
+const fdes_ctx* owner_ctx(const fdes_plan* pl) { return pl->parent_ctx ? pl->parent_ctx : pl->ctx; }
 
 #define HIPCHK(ctx, expr)                                                                         \
     do {                                                                                          \
@@ -202,12 +234,12 @@ int config_atoms(fdes_plan* pl, int k, int j)
     fdes_ctx* c = pl->ctx;
     RC(ensure_tilt(pl, k));
     if (pl->p.frPh > 0)
-        HIPCHK(c, geom_jitter(pl->xyzFP_d, pl->xyzK_d, pl->dwf_d, pl->nAt, c->seed, k, j, c->stream));
+        HIPCHK(c, geom_jitter(pl->xyzFP_d, pl->xyzK_d, pl->dwf_d, pl->nAt, owner_ctx(pl)->seed, k, j, c->stream));
     else
         HIPCHK(c, hipMemcpyAsync(pl->xyzFP_d, pl->xyzK_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, c->stream));
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
     HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, pl->fused, c->stream));
-    if (pl->fused && c->skip_empty) {
+    if (pl->fused && owner_ctx(pl)->skip_empty) {
         // which slices hold atoms decides the launch sequence: one small D2H per configuration
         pl->seg_h.resize((size_t)pl->p.m3 * pl->nZ + 1);
         HIPCHK(c, hipMemcpyAsync(pl->seg_h.data(), pl->bins.seg, sizeof(int) * pl->seg_h.size(), hipMemcpyDeviceToHost, c->stream));
@@ -350,7 +382,7 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
     // P4 (mask) and P6 (masked propagator): P4/P6 run only their live row groups, P3/P5 do not store the rows those
     // never read, P5 does not load the columns they never write (pre-zeroed at plan creation).
     const int md = m1 < m2 ? m1 : m2, band = md * md;
-    const int bs = (c->band_skip && m1 == m2) ? 1 : 0; // the column classes of the passes assume the band of a square grid
+    const int bs = (owner_ctx(pl)->band_skip && m1 == m2) ? 1 : 0; // the column classes of the passes assume the band of a square grid
     auto empty = [&](int q) { return q >= pl->p.m3 || pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ]; };
     const bool have_seg = !pl->seg_h.empty();
     if (have_seg && empty(s)) {
@@ -390,7 +422,7 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
     a5.in0 = pl->E; a5.in1 = pl->PSIH; a5.out = pl->F;
     a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
     // roofline probe: P5 is the longest kernel of the loop; every probe_stride-th launch is bracketed by events
-    const int pstride = pl->parent_ctx ? pl->parent_ctx->probe_stride : c->probe_stride;
+    const int pstride = owner_ctx(pl)->probe_stride;
     const bool probe = !pl->capturing && pstride > 0 && (pl->fft_calls++ % (uint64_t)pstride) == 0;
     EvPair* ev = nullptr;
     if (probe) {
@@ -424,7 +456,7 @@ int fused_leave(fdes_plan* pl, bool propagated)
 {
     PassArgs a = pass_x(pl);
     a.in0 = pl->PSIH; a.out = pl->PSI;
-    if (pl->ctx->band_skip && pl->p.m1 == pl->p.m2 && propagated) { // the dead columns were last written by fused_enter: they count as zero
+    if (owner_ctx(pl)->band_skip && pl->p.m1 == pl->p.m2 && propagated) { // the dead columns were last written by fused_enter: they count as zero
         const int md = pl->p.m1 < pl->p.m2 ? pl->p.m1 : pl->p.m2;
         a.band = md * md;
         a.skip_dead_loads = 1;
@@ -462,7 +494,7 @@ int slice_loop(fdes_plan* pl, int nslices)
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
     if (pl->fused) {
         fdes_ctx* c = pl->ctx;
-        const fdes_ctx* oc = pl->parent_ctx ? pl->parent_ctx : c; // lanes follow the owner's runtime options
+        const fdes_ctx* oc = owner_ctx(pl); // lanes follow the owner's runtime options
         const bool timing_probe = (oc->probe_stride > 0);
         if (!oc->opt_graph || timing_probe || nslices < 1) {
             RC(fused_enter(pl));
@@ -472,12 +504,18 @@ int slice_loop(fdes_plan* pl, int nslices)
         // key: slice count, band option and the empty-slice pattern (FNV-1a over one bit per slice)
         uint64_t key = 1469598103934665603ull;
         auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
-        mix((uint64_t)nslices);
-        mix((uint64_t)c->band_skip);
+        // the pattern itself (slice count, band option, one byte per slice) is kept beside its hash and compared on a
+        // hit: a colliding hash must not replay another pattern's launch sequence
+        std::vector<uint8_t> pattern;
+        pattern.reserve((size_t)pl->p.m3 + 8);
+        for (int b = 0; b < 4; b++) pattern.push_back((uint8_t)((unsigned)nslices >> (8 * b)));
+        pattern.push_back((uint8_t)oc->band_skip);
+        pattern.push_back(pl->seg_h.empty() ? 0 : 1);
         if (!pl->seg_h.empty())
-            for (int q = 0; q < pl->p.m3; q++) mix(pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ] ? 2u : 3u);
+            for (int q = 0; q < pl->p.m3; q++) pattern.push_back(pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ] ? 2 : 3);
+        for (uint8_t b : pattern) mix(b);
         fdes_plan::LoopGraph* g = nullptr;
-        for (auto& e : pl->graphs) if (e.key == key) g = &e;
+        for (auto& e : pl->graphs) if (e.key == key && e.pattern == pattern) g = &e;
         if (!g) {
             std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
             const int64_t skipped0 = pl->slices_skipped;
@@ -515,7 +553,7 @@ int slice_loop(fdes_plan* pl, int nslices)
                 for (auto& e : pl->graphs[lru].pow) (void)hipFree(e.second);
                 pl->graphs.erase(pl->graphs.begin() + (long)lru);
             }
-            pl->graphs.push_back({key, exec, skipped, 0, pow_owned});
+            pl->graphs.push_back({key, pattern, exec, skipped, 0, pow_owned});
             g = &pl->graphs.back();
         }
         g->used = ++pl->graph_tick;
@@ -580,6 +618,41 @@ int fold_lanes(fdes_plan* pl)
     return FDES_OK;
 }
 
+// configurations whose slice loop has finished on the GPU (this plan and its lanes); oldest_pending = the end event of
+// the oldest one still running, if any
+int64_t configs_finished(fdes_plan* pl, hipEvent_t* oldest_pending)
+{
+    int64_t n = 0;
+    auto scan = [&](fdes_plan* q) {
+        while (q->ev_done < q->ev_used && hipEventQuery(q->evs[q->ev_done].b) == hipSuccess) q->ev_done++;
+        (void)hipGetLastError(); // hipErrorNotReady is not an error
+        n += (int64_t)q->ev_done;
+        if (oldest_pending && !*oldest_pending && q->ev_done < q->ev_used) *oldest_pending = q->evs[q->ev_done].b;
+    };
+    scan(pl);
+    for (fdes_plan* l : pl->lanes) scan(l);
+    return n;
+}
+
+// rate-limited progress report of fdes_build_measurements; also bounds the number of configurations in flight
+void report_progress(fdes_plan* pl, int64_t issued, int64_t total_configs, bool final)
+{
+    fdes_ctx* c = pl->ctx;
+    if (!c->progress) return;
+    const int64_t depth = 2 * (int64_t)(pl->lanes.size() + 1);
+    int64_t done = 0;
+    for (;;) {
+        hipEvent_t pending = nullptr;
+        done = configs_finished(pl, &pending);
+        if ((!final && issued - done <= depth) || !pending) break;
+        (void)hipEventSynchronize(pending);
+    }
+    const auto now = std::chrono::steady_clock::now();
+    if (!final && std::chrono::duration_cast<std::chrono::milliseconds>(now - c->progress_last).count() < c->progress_min_ms) return;
+    c->progress_last = now;
+    c->progress(c->progress_user, done * (int64_t)pl->p.m3, total_configs * (int64_t)pl->p.m3);
+}
+
 int check_params(fdes_ctx* ctx, const fdes_params* p, const fdes_atoms* a)
 {
     if (!p || !a || !p->tiltspec || !p->tiltbeam || !p->defoci) { ctx->err = "null parameter / atom pointers"; return FDES_EINVAL; }
@@ -630,8 +703,27 @@ int create_ctx(fdes_ctx** out, int gpu_index, int prio_class)
         return FDES_EGPU;
     }
     std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+    // Registered AFTER the HIP runtime and rocFFT have initialised, so at process exit it runs BEFORE their own
+    // teardown (exit handlers run in reverse order of registration): whatever the host left open is closed while
+    // the runtime is still alive, instead of by a finaliser that runs after it is gone.
+    std::call_once(g_atexit_once, [] { std::atexit(shutdown_all); });
+    { std::lock_guard<std::mutex> g(g_live_mutex); g_live_ctx.insert(c); }
     *out = c;
     return FDES_OK;
+}
+
+void shutdown_all()
+{
+    for (;;) {
+        fdes_ctx* c = nullptr;
+        {
+            std::lock_guard<std::mutex> g(g_live_mutex);
+            for (const void* q : g_live_ctx)
+                if (!((const fdes_ctx*)q)->is_lane_ctx) { c = (fdes_ctx*)q; break; } // lane contexts go with their plan
+        }
+        if (!c) break;
+        (void)fdes_destroy(c);
+    }
 }
 } // namespace
 
@@ -639,16 +731,27 @@ int fdes_create(fdes_ctx** out, int gpu_index) { return create_ctx(out, gpu_inde
 
 int fdes_destroy(fdes_ctx* c)
 {
-    if (!c) return FDES_EINVAL;
+    if (!c || !live_ctx(c)) return FDES_EINVAL;
     (void)hipSetDevice(c->device);
+    while (!c->plans.empty()) (void)fdes_plan_destroy(c->plans.back()); // each call removes itself from the list
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->fft_cache) { kv.second->destroy(); delete kv.second; }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    { std::lock_guard<std::mutex> g(g_live_mutex); g_live_ctx.erase(c); }
     delete c;
     return FDES_OK;
 }
 
 const char* fdes_last_error(const fdes_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int fdes_set_progress(fdes_ctx* c, fdes_progress_fn fn, void* user, int min_interval_ms)
+{
+    if (!c || min_interval_ms < 0) return FDES_EINVAL;
+    c->progress = fn;
+    c->progress_user = user;
+    c->progress_min_ms = min_interval_ms;
+    return FDES_OK;
+}
 
 int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
 {
@@ -670,9 +773,11 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
 
 int fdes_plan_destroy(fdes_plan* pl)
 {
-    if (!pl) return FDES_EINVAL;
+    if (!pl || !live_plan(pl)) return FDES_EINVAL;
     std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
     fdes_ctx* c = pl->ctx;
+    { std::lock_guard<std::mutex> g(g_live_mutex); g_live_plan.erase(pl); }
+    c->plans.erase(std::remove(c->plans.begin(), c->plans.end(), pl), c->plans.end());
     (void)hipSetDevice(c->device);
     for (fdes_plan* l : pl->lanes) fdes_plan_destroy(l);
     for (fdes_ctx* lc : pl->lane_ctx) fdes_destroy(lc);
@@ -682,12 +787,13 @@ int fdes_plan_destroy(fdes_plan* pl)
     void* ptrs[] = {pl->Z_d, pl->spec_d, pl->xyz0_d, pl->xyzTO_d, pl->xyzK_d, pl->xyzFP_d, pl->dwf_d, pl->occ_d, pl->bins.keys,
                     pl->bins.keys_sorted, pl->bins.vals, pl->bins.order, pl->bins.seg, pl->bins.tmp, pl->bins.recs, pl->bins.recs_sorted, pl->bins.rowstart, pl->D, pl->VH, pl->T, pl->PSI,
                     pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A == pl->C ? nullptr : pl->A, pl->C, pl->C2, pl->E, pl->PSIH,
-                    pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT}; // F aliases C
+                    pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT, pl->peer_stage}; // F aliases C
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (auto& g : pl->graphs) { (void)hipGraphExecDestroy(g.exec); for (auto& e : g.pow) (void)hipFree(e.second); }
     for (auto& e : pl->pow_tabs) if (e.tab) (void)hipFree(e.tab);
     for (auto& e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : pl->probe) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (pl->peer_ev) (void)hipEventDestroy(pl->peer_ev);
     fdes_params_release(&pl->p0);
     delete pl;
     return FDES_OK;
@@ -704,6 +810,8 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     pl->ctx = c;
     int rc = fdes_params_clone(&pl->p0, p_in);
     if (rc) { delete pl; return rc; }
+    { std::lock_guard<std::mutex> g(g_live_mutex); g_live_plan.insert(pl); }
+    c->plans.push_back(pl);
     pl->p = pl->p0; // shares arrays
     pl->ratio = fdes_params_sub_slices(&pl->p); // src/crystalMaker.cu:246-247
     pl->kp = make_kp(pl->p);
@@ -776,7 +884,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLHIP(hipMemsetAsync(pl->EW, 0, sizeof(float2) * pl->m12, c->stream));
     PLHIP(hipMemsetAsync(pl->J, 0, sizeof(float) * (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3, c->stream));
     {
-        auto key = std::make_pair(pl->p.m1, pl->p.m2);
+        auto key = std::make_tuple(pl->p.m1, pl->p.m2, c->opt_fft);
         auto it = c->fft_cache.find(key);
         if (it == c->fft_cache.end()) {
             std::string ferr;
@@ -850,6 +958,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             fdes_ctx* lc = nullptr;
             PLCHK(create_ctx(&lc, c->device, nlanes >= 3 ? (l <= 2 ? l : 0) : 0));
             lc->is_lane_ctx = true;
+            // frozen here: fft, lanes, pass_threads (they shape the lane plan); the others are read through owner_ctx()
             lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip;
             lc->share_PT = pl->PT; lc->share_GT = pl->GT; // read-only tables of the parent plan (built and synchronised above)
             pl->lane_ctx.push_back(lc);
@@ -1014,6 +1123,7 @@ int fdes_plan_slice_loop_ms(fdes_plan* pl, double* total_ms, int64_t* slices)
         n += pl->evs[i].slices;
     }
     pl->ev_used = 0;
+    pl->ev_done = 0;
     for (fdes_plan* l : pl->lanes) {
         double tl = 0;
         int64_t nl = 0;
@@ -1051,6 +1161,81 @@ int fdes_plan_probe_ms(fdes_plan* pl, double* total_ms, int64_t* launches)
     if (launches) *launches = nl;
     return FDES_OK;
 }
+
+int fdes_plan_want_exitwave(fdes_plan* pl, int on)
+{
+    if (!pl) return FDES_EINVAL;
+    pl->want_ew = on != 0;
+    return FDES_OK;
+}
+
+int fdes_plan_get_exitwave(fdes_plan* pl, float* ew)
+{
+    if (!pl || !ew || !pl->want_ew) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    RC(fold_lanes(pl));
+    HIPCHK(c, hipMemcpyAsync(ew, pl->EW, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDES_OK;
+}
+
+// The sum over configurations of src/crystalMaker.cu:347-365 when a measurement spans GPUs: dst.I += src.I (and the
+// coherent exit-wave sum when wanted), device to device.  The source's partial sum crosses xGMI once
+// (hipMemcpyPeerAsync into a landing buffer on dst's GPU, ordered behind src's stream by an event) and is added by one
+// axpy kernel on dst's stream; on one GPU the axpy reads the source directly.  Synchronises dst's stream, so the
+// caller may let src continue afterwards.
+int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src)
+{
+    if (!dst || !src || dst == src || dst->m12 != src->m12) return FDES_EINVAL;
+    fdes_ctx *dc = dst->ctx, *sc = src->ctx;
+    HIPCHK(sc, hipSetDevice(sc->device));
+    RC(fold_lanes(src));
+    if (!src->peer_ev) HIPCHK(sc, hipEventCreateWithFlags(&src->peer_ev, hipEventDisableTiming));
+    HIPCHK(sc, hipEventRecord(src->peer_ev, sc->stream));
+    HIPCHK(dc, hipSetDevice(dc->device));
+    RC(fold_lanes(dst));
+    HIPCHK(dc, hipStreamWaitEvent(dc->stream, src->peer_ev, 0));
+    const bool same = dc->device == sc->device;
+    if (!same && !dst->peer_stage) {
+        std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc vs a capture in another thread
+        RC(dmalloc(dc, &dst->peer_stage, dst->m12));
+    }
+    const int nsum = (dst->want_ew && src->want_ew) ? 2 : 1;
+    for (int q = 0; q < nsum; q++) {
+        float2* acc = q ? dst->EW : dst->I;
+        const float2* part = q ? src->EW : src->I;
+        if (!same) {
+            HIPCHK(dc, hipMemcpyPeerAsync(dst->peer_stage, dc->device, part, sc->device, sizeof(float2) * dst->m12, dc->stream));
+            part = dst->peer_stage;
+        }
+        HIPCHK(dc, k_axpy(acc, part, dst->m12, 1.f, dc->stream));
+    }
+    HIPCHK(dc, hipStreamSynchronize(dc->stream));
+    return FDES_OK;
+}
+
+// Potential output of print_level > 0 (src/crystalMaker.cu:381-397): tilt-offset-only, un-jittered potential of the
+// ORIGINAL slices [s_lo, s_hi) (setSubSlices(1 / ratio)) into potential[(s - s_lo) * 2 m1 m2 ...].  Always computed
+// (the reference leaves it uninitialised when ratio == 1, frPh == 0 and the last specimen tilt is zero).
+int fdes_plan_potential(fdes_plan* pl, int s_lo, int s_hi, float* potential)
+{
+    if (!pl || !potential) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    const float inv = 1.f / (float)pl->ratio;
+    BinGeom g{pl->p.m1, pl->p.m2, (int)(((float)pl->p.m3) * inv), pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3 / inv};
+    if (s_lo < 0 || s_hi > g.m3 || s_lo > s_hi) return FDES_EINVAL;
+    HIPCHK(c, geom_bin_atoms(pl->xyzTO_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, false, c->stream));
+    for (int s = s_lo; s < s_hi; s++) {
+        RC(phase_grating(pl, pl->xyzTO_d, g, s));
+        HIPCHK(c, hipMemcpyAsync(potential + 2 * pl->m12 * (size_t)(s - s_lo), pl->VH, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return FDES_OK;
+}
+
+int fdes_plan_original_slices(const fdes_plan* pl) { return pl ? (int)(((float)pl->p.m3) * (1.f / (float)pl->ratio)) : FDES_EINVAL; }
 
 // ------------------------------- stage taps (parity tests) -------------------------------------
 
@@ -1125,7 +1310,7 @@ int fdes_plan_propagate_dev(fdes_plan* pl, void* psi_dev, const void* t_dev, int
         // rows y: IFFT_x.  The x round trip is unnormalised (m1) and P carries 1 / (m1 m2): the last pass scales by 1.
         const int m1 = pl->p.m1, m2 = pl->p.m2;
         const int md = m1 < m2 ? m1 : m2, band = md * md;
-        const int bs = (c->band_skip && m1 == m2) ? 1 : 0;
+        const int bs = (owner_ctx(pl)->band_skip && m1 == m2) ? 1 : 0;
         for (int b = 0; b < batch; b++) {
             float2* psi = (float2*)psi_dev + (size_t)b * pl->m12;
             const float2* t = (const float2*)t_dev + (t_per_wave ? (size_t)b * pl->m12 : 0);
@@ -1250,33 +1435,16 @@ int fdes_build_measurements(fdes_ctx* c, const fdes_params* p, const fdes_atoms*
     int rc = FDES_OK;
     for (int k = 0; k < pl->p.n3 && rc == FDES_OK; k++) {
         rc = fdes_plan_begin_measurement(pl, k);
-        for (int j = 0; j < count && rc == FDES_OK; j++) rc = fdes_plan_run_config(pl, k, j, alpha);
-        if (rc == FDES_OK && exitwave) rc = fold_lanes(pl);
-        if (rc == FDES_OK && exitwave) {
-            hipError_t e = hipMemcpyAsync(exitwave + 2 * pl->m12 * (size_t)k, pl->EW, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = FDES_EGPU; }
+        for (int j = 0; j < count && rc == FDES_OK; j++) {
+            rc = fdes_plan_run_config(pl, k, j, alpha);
+            if (rc == FDES_OK) report_progress(pl, (int64_t)k * count + j + 1, (int64_t)pl->p.n3 * count, false);
         }
+        if (rc == FDES_OK && exitwave) rc = fdes_plan_get_exitwave(pl, exitwave + 2 * pl->m12 * (size_t)k);
         if (rc == FDES_OK) rc = fdes_plan_end_measurement(pl, k);
     }
     if (rc == FDES_OK) rc = fdes_plan_get_images(pl, image);
-    if (rc == FDES_OK && potential) {
-        // src/crystalMaker.cu:381-397: tilt-offset-only, un-jittered potential per ORIGINAL slice
-        // (setSubSlices(1/ratio)).  Always computed (the reference leaves it uninitialised when
-        // ratio == 1, frPh == 0 and the last specimen tilt is zero).
-        const float inv = 1.f / (float)pl->ratio;
-        BinGeom g{pl->p.m1, pl->p.m2, (int)(((float)pl->p.m3) * inv), pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3 / inv};
-        hipError_t e = geom_bin_atoms(pl->xyzTO_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, false, c->stream);
-        if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = FDES_EGPU; }
-        for (int s = 0; s < g.m3 && rc == FDES_OK; s++) {
-            rc = phase_grating(pl, pl->xyzTO_d, g, s);
-            if (rc == FDES_OK) {
-                e = hipMemcpyAsync(potential + 2 * pl->m12 * (size_t)s, pl->VH, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-                if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = FDES_EGPU; }
-            }
-        }
-    }
+    if (rc == FDES_OK) report_progress(pl, (int64_t)pl->p.n3 * count, (int64_t)pl->p.n3 * count, true);
+    if (rc == FDES_OK && potential) rc = fdes_plan_potential(pl, 0, fdes_plan_original_slices(pl), potential);
     fdes_plan_destroy(pl);
     return rc;
 }

@@ -21,7 +21,9 @@
 #include "fft_lds.h"
 #include "geometry.h"
 
+#include <atomic>
 #include <cmath>
+#include <type_traits>
 
 namespace fdes {
 
@@ -151,6 +153,62 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c)
     const float c_ = (k & 1) ? sn : cs;
     s = (k & 2) ? -s_ : s_;
     c = ((k + 1) & 2) ? -c_ : c_;
+}
+
+// Outside that range (|x| > kSincosFast: no physical specimen, but nothing in the input format forbids it) the
+// reduction is done in double precision against a two-word pi/2: exact to < 1e-7 rad up to |x| ~ 1e9, no Payne-Hanek
+// tables, a handful of registers.  The pass kernels test their 32 phases once and take this path as a whole.
+constexpr float kSincosFast = 1.0e3f;
+__device__ __forceinline__ void sincos_wide(float x, float& s, float& c)
+{
+    const double xd = (double)x;
+    const double kd = rint(xd * 0.63661977236758134308);
+    double rd = fma(-kd, 1.57079632679489655800e+00, xd);
+    rd = fma(-kd, 6.12323399573676603587e-17, rd);
+    const int k = (int)(long long)kd; // |kd| < 2^31 for |x| < 3.3e9; beyond that float phases carry no information
+    const float r = (float)rd;
+    const float r2 = r * r;
+    float sp = 2.75573192e-6f;
+    sp = fmaf(sp, r2, -1.98412701e-4f);
+    sp = fmaf(sp, r2, 8.33333377e-3f);
+    sp = fmaf(sp, r2, -1.66666672e-1f);
+    const float sn = fmaf(r * r2, sp, r);
+    float cp = 2.48015876e-5f;
+    cp = fmaf(cp, r2, -1.38888892e-3f);
+    cp = fmaf(cp, r2, 4.16666679e-2f);
+    cp = fmaf(cp, r2, -0.5f);
+    const float cs = fmaf(cp, r2, 1.0f);
+    const float s_ = (k & 1) ? cs : sn;
+    const float c_ = (k & 1) ? sn : cs;
+    s = (k & 2) ? -s_ : s_;
+    c = ((k + 1) & 2) ? -c_ : c_;
+}
+template <bool WIDE> __device__ __forceinline__ void sincos_sel(float x, float& s, float& c)
+{
+    if constexpr (WIDE) sincos_wide(x, s, c);
+    else sincos_cw(x, s, c);
+}
+
+// v -> f(v) on every element a thread holds, with the fast sine/cosine while all of its phases are small (the only
+// case a physical specimen produces) and the wide-range one otherwise; `mag` returns |phase| of an element.
+template <int NRV, class F, class M> __device__ __forceinline__ void expiv_all(cf (&a)[NRV][16], F f, M mag)
+{
+    float big = 0.f;
+#pragma unroll
+    for (int h = 0; h < NRV; h++)
+#pragma unroll
+        for (int l = 0; l < 16; l++) big = fmaxf(big, mag(a[h][l]));
+    if (__builtin_expect(big <= kSincosFast, 1)) {
+#pragma unroll
+        for (int h = 0; h < NRV; h++)
+#pragma unroll
+            for (int l = 0; l < 16; l++) a[h][l] = f(a[h][l], std::false_type{});
+    } else {
+#pragma unroll
+        for (int h = 0; h < NRV; h++) // unrolled as well: a runtime index would send the whole register array to scratch
+#pragma unroll
+            for (int l = 0; l < 16; l++) a[h][l] = f(a[h][l], std::true_type{});
+    }
 }
 
 __device__ __forceinline__ int iwc(int i, int m) { return (i > m / 2) ? i - m : i; } // iwCoordIp
@@ -544,41 +602,35 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
         if constexpr (MID == MID_MULPSI && FDES_P5_PREFETCH) load_rows<N, WG>(b, in1, rbase, t, A.skip_dead_loads != 0);
         xform<N, WG, PRE, false, TWR>(a, lds, r, t, tw, gs);
         if constexpr (MID == MID_EXPIV) {
-#pragma unroll
-            for (int h = 0; h < WGeo<WG>::NRV; h++)
-#pragma unroll
-                for (int l = 0; l < 16; l++) {
-                    const float e = __expf(-a[h][l].y);
-                    float sn, cs;
-                    sincos_cw(a[h][l].x, sn, cs);
-                    a[h][l] = make_float2(e * cs, e * sn);
-                }
+            expiv_all(a, [&](float2 v, auto wide) {
+                const float e = __expf(-v.y);
+                float sn, cs;
+                sincos_sel<decltype(wide)::value>(v.x, sn, cs);
+                return make_float2(e * cs, e * sn);
+            }, [](float2 v) { return fabsf(v.x); });
         } else if constexpr (MID == MID_EXPIV_RE || MID == MID_EXPIV_IM) {
             // two slices share one potential grid: V_s = Re, V_{s+1} = Im; absorption V.y = imPot * V.x
-#pragma unroll
-            for (int h = 0; h < WGeo<WG>::NRV; h++)
-#pragma unroll
-                for (int l = 0; l < 16; l++) {
-                    const float v = (MID == MID_EXPIV_RE) ? a[h][l].x : a[h][l].y;
-                    const float e = __expf(-(v * A.scale));
-                    float sn, cs;
-                    sincos_cw(v, sn, cs);
-                    a[h][l] = make_float2(e * cs, e * sn);
-                }
+            expiv_all(a, [&](float2 w, auto wide) {
+                const float v = (MID == MID_EXPIV_RE) ? w.x : w.y;
+                const float e = __expf(-(v * A.scale));
+                float sn, cs;
+                sincos_sel<decltype(wide)::value>(v, sn, cs);
+                return make_float2(e * cs, e * sn);
+            }, [](float2 w) { return (MID == MID_EXPIV_RE) ? fabsf(w.x) : fabsf(w.y); });
         } else if constexpr (MID == MID_EXPIV_PAIR) {
             // transmission function of the first slice now; the second slice's potential (one float per pixel) waits
             // in registers until the first result has been transformed and stored
 #pragma unroll
             for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
-                for (int l = 0; l < 16; l++) {
-                    const float v0 = a[h][l].x;
-                    vim[h][l] = a[h][l].y;
-                    float sn, cs;
-                    const float e0 = __expf(-(v0 * A.scale));
-                    sincos_cw(v0, sn, cs);
-                    a[h][l] = make_float2(e0 * cs, e0 * sn);
-                }
+                for (int l = 0; l < 16; l++) vim[h][l] = a[h][l].y;
+            expiv_all(a, [&](float2 w, auto wide) {
+                const float v0 = w.x;
+                float sn, cs;
+                const float e0 = __expf(-(v0 * A.scale));
+                sincos_sel<decltype(wide)::value>(v0, sn, cs);
+                return make_float2(e0 * cs, e0 * sn);
+            }, [](float2 w) { return fabsf(w.x); });
         } else if constexpr (MID == MID_MASK) {
             // zeroHighFreq tests (float)(i1^2 + i2^2) * 9 / mindim^2 > 1 (src/multisliceSimulation.cu:241).  On the
             // power-of-two grids this kernel serves, mindim^2 < 2^24, so every float on the deciding side of the
@@ -669,13 +721,14 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
 #pragma unroll
         for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
-            for (int l = 0; l < 16; l++) {
-                const float v1 = vim[h][l];
-                float sn, cs;
-                const float e1 = __expf(-(v1 * A.scale));
-                sincos_cw(v1, sn, cs);
-                a[h][l] = make_float2(e1 * cs, e1 * sn);
-            }
+            for (int l = 0; l < 16; l++) a[h][l].x = vim[h][l];
+        expiv_all(a, [&](float2 w, auto wide) {
+            const float v1 = w.x;
+            float sn, cs;
+            const float e1 = __expf(-(v1 * A.scale));
+            sincos_sel<decltype(wide)::value>(v1, sn, cs);
+            return make_float2(e1 * cs, e1 * sn);
+        }, [](float2 w) { return fabsf(w.x); });
         __syncthreads(); // every wave is done with the transpose tile before the second transform writes the row buffers
         xform<N, WG, POST, true, TWR>(a, lds, r, t, tw, gs);
         store_rows(a, reinterpret_cast<float2*>(A.out2));
@@ -688,13 +741,21 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
 template <int N, int WG, int PRE, int MID, int POST, bool ST> hipError_t launch(const PassArgs& a, hipStream_t st)
 {
     using G_ = Geo<N, WG>;
-    static bool attr_set = false;
+    // The dynamic-LDS limit (69-139 KB, above the 64 KB default) is a property of the function ON ONE DEVICE: one bit
+    // per device, set by whichever host thread launches this instantiation there first (fetch_or: two threads racing on
+    // the same device both make the call, which is idempotent).
+    static std::atomic<unsigned long long> attr_set{0};
     constexpr size_t lds_bytes = sizeof(float2) * (size_t)G_::LDROW * G_::R + 64;
     auto kern = k_pass<N, WG, PRE, MID, POST, ST>;
-    if (!attr_set) {
+    int dev = 0;
+    {
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+    }
+    if (dev < 0 || dev >= 64 || !((attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
     if (a.nrows % G_::R != 0) return hipErrorInvalidValue;
     int groups = a.nrows / G_::R;

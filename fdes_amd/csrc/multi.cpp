@@ -1,10 +1,12 @@
 // multi.cpp — buildMeasurements over several GPUs of one node from ONE host process (one host thread per GPU), written
 // against the public C-ABI only (what a maintainer of the reference's C++ host would write).  The (k, j) wave
 // propagations of src/crystalMaker.cu:324-367 are independent; the flattened list is block-partitioned over the GPUs
-// exactly as fdes_amd/shard.py does for the one-process-per-GPU launch, the partial intensity sums of a measurement k
-// that spans GPUs are added in ascending GPU order (host-staged: 8 m1 m2 bytes per GPU and k, off the hot path) and the
-// owner of k applies addNoiseAndMtf.  Random numbers are keyed on (k, j): the images do not depend on the partition
-// beyond the association order of that one sum.
+// exactly as fdes_amd/shard.py does for the one-process-per-GPU launch.  The partial sums of a measurement k that spans
+// GPUs (intensity; the coherent exit-wave sum when asked for) are added on the OWNER's GPU in ascending GPU order: one
+// peer copy over xGMI and one axpy kernel per contributing GPU (fdes_plan_accumulate_from; src/crystalMaker.cu:347-365
+// is the sum being distributed), then the owner applies addNoiseAndMtf.  The potential output (print_level > 0) does
+// not depend on (k, j): its slices are dealt over the GPUs.  Random numbers are keyed on (k, j): the images do not
+// depend on the partition beyond the association order of that one sum.
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -45,32 +47,33 @@ Part part_of(int total, int world, int rank)
 
 } // namespace
 
-extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const fdes_params* p, const fdes_atoms* a, float* image)
+extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const fdes_params* p, const fdes_atoms* a, float* image,
+                                             float* potential, float* exitwave)
 {
     if (ngpu < 1 || !devices || !p || !a || !image) return FDES_EINVAL;
     if (ngpu == 1) {
         fdes_ctx* c = nullptr;
         int rc = fdes_create(&c, devices[0]);
         if (rc) return rc;
-        rc = fdes_build_measurements(c, p, a, image, nullptr, nullptr);
+        rc = fdes_build_measurements(c, p, a, image, potential, exitwave);
         fdes_destroy(c);
         return rc;
     }
     const int n3 = p->n3, count = p->frPh > 0 ? p->frPh : 1, total = n3 * count;
     const float weight = 1.f / (float)count; // alpha of src/crystalMaker.cu:302-304
     const size_t m12 = (size_t)p->m1 * (size_t)p->m2, img = (size_t)p->n1 * (size_t)p->n2;
-    // owner[k] = GPU that holds (k, 0); span[k] = [first, last] GPU holding any (k, j)
-    std::vector<int> owner((size_t)n3, 0), first((size_t)n3, ngpu), last((size_t)n3, -1);
+    // first[k] .. last[k] = GPUs holding any (k, j); the block partition is contiguous, so the owner of k (the GPU
+    // that holds (k, 0)) is first[k]
+    std::vector<int> first((size_t)n3, ngpu), last((size_t)n3, -1);
     for (int r = 0; r < ngpu; r++) {
         const Part q = part_of(total, ngpu, r);
         for (int i = q.lo; i < q.hi; i++) {
             const int k = i / count;
-            if (i % count == 0) owner[(size_t)k] = r;
             if (r < first[(size_t)k]) first[(size_t)k] = r;
             if (r > last[(size_t)k]) last[(size_t)k] = r;
         }
     }
-    std::vector<std::vector<float>> partial((size_t)ngpu);
+    std::vector<fdes_plan*> plans((size_t)ngpu, nullptr); // read by the owner between the two barriers of a split k
     std::vector<int> status((size_t)ngpu, FDES_OK);
     Barrier bar(ngpu);
     auto worker = [&](int r) {
@@ -79,44 +82,42 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
         fdes_plan* pl = nullptr;
         rc = fdes_create(&ctx, devices[r]);
         if (rc == FDES_OK) rc = fdes_plan_create(ctx, p, a, &pl);
+        if (rc == FDES_OK && exitwave) rc = fdes_plan_want_exitwave(pl, 1);
+        plans[(size_t)r] = rc == FDES_OK ? pl : nullptr;
         const Part q = part_of(total, ngpu, r);
         std::vector<float> mine;
         for (int k = 0; k < n3; k++) {
             const bool split = last[(size_t)k] > first[(size_t)k];
             const bool in_span = r >= first[(size_t)k] && r <= last[(size_t)k];
+            const bool owner = first[(size_t)k] == r;
             const int jlo = (q.lo > k * count ? q.lo : k * count), jhi = (q.hi < (k + 1) * count ? q.hi : (k + 1) * count);
             if (rc == FDES_OK && in_span) {
                 rc = fdes_plan_begin_measurement(pl, k);
                 for (int i = jlo; i < jhi && rc == FDES_OK; i++) rc = fdes_plan_run_config(pl, k, i % count, weight);
             }
             if (split) { // every thread passes both barriers, whatever its state, so that nobody waits for ever
-                if (rc == FDES_OK && in_span) {
-                    partial[(size_t)r].resize(2 * m12);
-                    rc = fdes_plan_copy_intensity(pl, partial[(size_t)r].data(), 0);
-                }
-                bar.wait();
-                if (rc == FDES_OK && owner[(size_t)k] == r) {
-                    std::vector<float>& sum = partial[(size_t)first[(size_t)k]]; // ascending GPU order
-                    bool ok = sum.size() == 2 * m12;
-                    for (int s = first[(size_t)k] + 1; s <= last[(size_t)k] && ok; s++) {
-                        const std::vector<float>& o = partial[(size_t)s];
-                        ok = o.size() == 2 * m12;
-                        for (size_t i = 0; ok && i < 2 * m12; i++) sum[i] += o[i];
-                    }
-                    rc = ok ? fdes_plan_copy_intensity(pl, sum.data(), 1) : FDES_EGPU; // a peer failed
-                }
-                bar.wait();
-                partial[(size_t)r].clear();
+                if (rc != FDES_OK) plans[(size_t)r] = nullptr;
+                bar.wait(); // the peers' configurations are enqueued; accumulate_from orders behind them with an event
+                if (rc == FDES_OK && owner)
+                    for (int s = first[(size_t)k] + 1; s <= last[(size_t)k] && rc == FDES_OK; s++) // ascending GPU order
+                        rc = plans[(size_t)s] ? fdes_plan_accumulate_from(pl, plans[(size_t)s]) : FDES_EGPU; // a peer failed
+                bar.wait(); // the peers' sums have been read: they may start their next measurement
             }
-            if (rc == FDES_OK && owner[(size_t)k] == r) rc = fdes_plan_end_measurement(pl, k);
+            if (rc == FDES_OK && owner && exitwave) rc = fdes_plan_get_exitwave(pl, exitwave + 2 * m12 * (size_t)k);
+            if (rc == FDES_OK && owner) rc = fdes_plan_end_measurement(pl, k);
         }
         if (rc == FDES_OK) {
             mine.resize(img * (size_t)n3);
             rc = fdes_plan_get_images(pl, mine.data());
             for (int k = 0; k < n3 && rc == FDES_OK; k++)
-                if (owner[(size_t)k] == r) std::memcpy(image + (size_t)k * img, mine.data() + (size_t)k * img, sizeof(float) * img);
+                if (first[(size_t)k] == r) std::memcpy(image + (size_t)k * img, mine.data() + (size_t)k * img, sizeof(float) * img);
+        }
+        if (rc == FDES_OK && potential) { // original slices dealt over the GPUs
+            const Part ps = part_of(fdes_plan_original_slices(pl), ngpu, r);
+            if (ps.hi > ps.lo) rc = fdes_plan_potential(pl, ps.lo, ps.hi, potential + 2 * m12 * (size_t)ps.lo);
         }
         if (rc != FDES_OK) std::fprintf(stderr, "  FDES: worker %d (device %d) failed with %d: %s\n", r, devices[r], rc, ctx ? fdes_last_error(ctx) : "no context");
+        bar.wait(); // nobody destroys a plan that a late accumulate_from of another thread could still name
         if (pl) fdes_plan_destroy(pl);
         if (ctx) fdes_destroy(ctx);
     };

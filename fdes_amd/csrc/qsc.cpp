@@ -103,12 +103,14 @@ int z_number(const std::string& line)
     char e[3] = {line.size() > 0 ? line[0] : '\0', line.size() > 1 ? line[1] : '\0', '\0'};
     if (e[0] == '\0') return 0;
     if (std::atoi(e + 1) != 0 || e[1] == '\n' || e[1] == '\0' || e[1] == '\r') e[1] = ' ';
-    static std::string table;
-    if (table.empty())
+    static const std::string table = [] { // initialised once, thread-safe (C++11 static)
+        std::string t;
         for (const char* s : kSymbols) {
-            table += s;
-            if (std::strlen(s) == 1) table += ' ';
+            t += s;
+            if (std::strlen(s) == 1) t += ' ';
         }
+        return t;
+    }();
     size_t at = table.find(e);
     return at == std::string::npos ? 0 : (int)(at / 2) + 1;
 }

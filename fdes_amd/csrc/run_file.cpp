@@ -10,6 +10,12 @@
 
 namespace {
 bool has_ext(const char* name, const char* ext) { return std::strstr(name, ext) != nullptr; }
+void print_progress(void*, int64_t done, int64_t total)
+{
+    if (total <= 0) return;
+    std::fprintf(stderr, "\r Progress: %d%%%s", (int)(100 * done / total), done == total ? "\n" : "");
+    std::fflush(stderr);
+}
 }
 
 extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_name, const char* image_name,
@@ -53,7 +59,7 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     std::vector<float> image, potential, exitwave;
     fdes_ctx* ctx = nullptr;
     // Extension: FDES_DEVICES="0,1,2,3" (or FDES_NUM_GPUS=n: devices gpu_index ... gpu_index + n - 1) spreads the
-    // (measurement, phonon configuration) pairs over several GPUs; print_level 0 only (images).
+    // (measurement, phonon configuration) pairs over several GPUs (every print_level).
     std::vector<int> devices;
     if (const char* e = std::getenv("FDES_DEVICES")) {
         for (const char* q = e; *q;) {
@@ -66,15 +72,21 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     } else if (const char* e = std::getenv("FDES_NUM_GPUS")) {
         for (int i = 0; i < std::atoi(e); i++) devices.push_back(gpu_index + i);
     }
-    if (rc == FDES_OK && devices.size() > 1 && print_level == 0) {
+    if (rc == FDES_OK && devices.size() > 1) {
+        const size_t m12 = (size_t)p0.m1 * p0.m2;
         image.resize((size_t)p0.n1 * p0.n2 * p0.n3);
+        if (print_level > 0) potential.resize(2 * m12 * (size_t)p0.m3);
+        if (print_level > 1) exitwave.resize(2 * m12 * (size_t)p0.n3);
         std::fprintf(stderr, "  FDES: %zu GPUs\n", devices.size());
-        rc = fdes_build_measurements_multi((int)devices.size(), devices.data(), &p0, &atoms, image.data());
+        rc = fdes_build_measurements_multi((int)devices.size(), devices.data(), &p0, &atoms, image.data(),
+                                           print_level > 0 ? potential.data() : nullptr, print_level > 1 ? exitwave.data() : nullptr);
         if (rc) std::fprintf(stderr, "  FDES: multi-GPU simulation failed (%d)\n", rc);
     } else {
     if (rc == FDES_OK) {
         rc = fdes_create(&ctx, gpu_index);
         if (rc) std::fprintf(stderr, "  FDES: no usable GPU with index %d\n", gpu_index);
+        // progressCounter, src/optimFunctions.cu:257: a percentage on stderr (FDES_QUIET=1 turns it off)
+        else if (!std::getenv("FDES_QUIET")) fdes_set_progress(ctx, print_progress, nullptr, 250);
     }
     if (rc == FDES_OK) {
         const size_t m12 = (size_t)p0.m1 * p0.m2;

@@ -136,10 +136,13 @@ int fdes_build_measurements(fdes_ctx* ctx, const fdes_params* p, const fdes_atom
                             float* image, float* potential, float* exitwave);
 
 /* The same over `ngpu` GPUs of one node from one host process (one host thread per device in `devices`): the (k, j)
- * configurations of src/crystalMaker.cu:324-367 are block-partitioned over the GPUs, partial intensity sums of a
- * measurement that spans GPUs are added in ascending order of the list, its first GPU applies addNoiseAndMtf.  Images
- * only (the potential / exit-wave outputs of print_level > 0 stay on the single-GPU call). */
-int fdes_build_measurements_multi(int ngpu, const int* devices, const fdes_params* p, const fdes_atoms* atoms, float* image);
+ * configurations of src/crystalMaker.cu:324-367 are block-partitioned over the GPUs; the partial sums of a measurement
+ * that spans GPUs (intensity, and the coherent exit-wave sum of print_level > 1, :347-365) are added ON THE OWNER'S GPU in
+ * ascending order of the list (fdes_plan_accumulate_from: peer copy over xGMI + one axpy per peer), the owner applies
+ * addNoiseAndMtf.  potential (may be NULL, print_level > 0): its slices are dealt over the GPUs as well.
+ * exitwave (may be NULL, print_level > 1). */
+int fdes_build_measurements_multi(int ngpu, const int* devices, const fdes_params* p, const fdes_atoms* atoms, float* image,
+                                  float* potential, float* exitwave);
 
 /* ---- resident interface: the same loops, split so that inputs stay in HBM and the
  * (k, j) configurations can be sharded over GPUs (src/crystalMaker.cu:324-373) ---- */
@@ -164,6 +167,18 @@ int fdes_plan_intensity_ptr(fdes_plan* plan, void** dev_ptr, size_t* bytes);
  * fdes_plan_intensity_ptr reports; stream-ordered with the plan's work, synchronises before return.
  * Lets a host runtime (torch.distributed / RCCL) reduce I without aliasing library memory. */
 int fdes_plan_copy_intensity(fdes_plan* plan, void* dev_buf, int to_plan);
+/* dst.I += src.I (and dst's exit-wave sum += src's when both plans want it), device to device: the reduction of
+ * src/crystalMaker.cu:347-365 for a measurement whose configurations ran on two plans.  Plans on different GPUs of
+ * the process: one peer copy into a landing buffer on dst's GPU + one axpy kernel.  Synchronises dst. */
+int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src);
+/* Coherent exit-wave average (print_level > 1, src/crystalMaker.cu:347,370): switch the accumulation on before
+ * fdes_plan_begin_measurement; fdes_plan_get_exitwave copies the sum of the current measurement, float[2*m1*m2]. */
+int fdes_plan_want_exitwave(fdes_plan* plan, int on);
+int fdes_plan_get_exitwave(fdes_plan* plan, float* exitwave);
+/* Potential output of print_level > 0 (src/crystalMaker.cu:381-397) for the ORIGINAL slices [s_lo, s_hi):
+ * float[2*m1*m2*(s_hi - s_lo)].  fdes_plan_original_slices = m3 before sub-slicing. */
+int fdes_plan_potential(fdes_plan* plan, int s_lo, int s_hi, float* potential);
+int fdes_plan_original_slices(const fdes_plan* plan);
 /* Device pointer to J (float[n1*n2*n3]). */
 int fdes_plan_images_ptr(fdes_plan* plan, void** dev_ptr, size_t* bytes);
 /* D2H of J (:375). Synchronises. */
@@ -226,6 +241,15 @@ int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_
  *                dealt round-robin to lanes, partial intensity sums are folded in end_measurement
  *   "pass_threads"  0 auto, 256 or 512 threads per LDS-pass workgroup                        */
 int fdes_set_option(fdes_ctx* ctx, const char* key, int64_t value);
+
+/* Progress report.  The reference prints a percentage to stderr from inside its slice loop (progressCounter,
+ * src/optimFunctions.cu:257, called at src/crystalMaker.cu:341 with j = slice-propagations started, jTot = n3 * count * m3).
+ * Here fdes_build_measurements calls `fn(user, done, total)` on the calling host thread, between configurations (never
+ * from a captured graph), at most once per `min_interval_ms` and once at the end; `done` counts slice-propagations whose
+ * configuration has FINISHED on the GPU.  With a callback installed at most 2 x lanes configurations are kept in
+ * flight.  fn = NULL removes it. */
+typedef void (*fdes_progress_fn)(void* user, int64_t done, int64_t total);
+int fdes_set_progress(fdes_ctx* ctx, fdes_progress_fn fn, void* user, int min_interval_ms);
 
 /* ---------------- legacy symbol ---------------- */
 /* src/FDESExport.cu:59-60.  Same arguments; returns normally on error after printing to

@@ -1,0 +1,125 @@
+// multi_tsan.cpp — ThreadSanitizer harness for fdes_amd/csrc/multi.cpp (the one-process multi-GPU driver).
+// TEST INFRASTRUCTURE.  multi.cpp is written against the public C-ABI only, so it links here against STUB plans that
+// keep their "intensity" in host memory: every entry point multi.cpp calls is implemented below with plain loads and
+// stores and NO locking, so any pair of calls that the driver's barriers fail to order shows up as a data race.  The
+// result is also compared with the serial sum (partition + ownership logic).
+// Build + run: tests/test_host_cpu.py::test_multi_gpu_driver_under_thread_sanitizer
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fdes_abi.h"
+
+struct fdes_ctx { int device; };
+struct fdes_plan {
+    fdes_ctx* ctx;
+    int n1, n2, n3, m3, count;
+    size_t m12;
+    std::vector<float> I, EW, J;
+    bool want_ew = false;
+    int cur_k = -1;
+};
+
+static float contrib(int k, int j, size_t i) { return (float)((k * 131 + j * 17 + (int)(i % 97)) % 251) / 251.0f; }
+
+extern "C" {
+int fdes_create(fdes_ctx** c, int dev) { *c = new fdes_ctx{dev}; return dev < 0 ? FDES_EGPU : FDES_OK; }
+int fdes_destroy(fdes_ctx* c) { delete c; return FDES_OK; }
+const char* fdes_last_error(const fdes_ctx*) { return "stub"; }
+int fdes_build_measurements(fdes_ctx*, const fdes_params*, const fdes_atoms*, float*, float*, float*) { return FDES_EUNSUPPORTED; }
+int fdes_plan_create(fdes_ctx* c, const fdes_params* p, const fdes_atoms*, fdes_plan** out)
+{
+    fdes_plan* pl = new fdes_plan();
+    pl->ctx = c; pl->n1 = p->n1; pl->n2 = p->n2; pl->n3 = p->n3; pl->m3 = p->m3; pl->count = p->frPh > 0 ? p->frPh : 1;
+    pl->m12 = (size_t)p->m1 * p->m2;
+    pl->I.assign(2 * pl->m12, 0.f); pl->EW.assign(2 * pl->m12, 0.f); pl->J.assign((size_t)p->n1 * p->n2 * p->n3, 0.f);
+    *out = pl;
+    return c->device == 99 ? FDES_ENOMEM : FDES_OK; // device 99: a worker that fails at plan creation
+}
+int fdes_plan_destroy(fdes_plan* pl) { delete pl; return FDES_OK; }
+int fdes_plan_want_exitwave(fdes_plan* pl, int on) { pl->want_ew = on != 0; return FDES_OK; }
+int fdes_plan_begin_measurement(fdes_plan* pl, int k)
+{
+    std::fill(pl->I.begin(), pl->I.end(), 0.f);
+    std::fill(pl->EW.begin(), pl->EW.end(), 0.f);
+    pl->cur_k = k;
+    return FDES_OK;
+}
+int fdes_plan_run_config(fdes_plan* pl, int k, int j, float w)
+{
+    for (size_t i = 0; i < pl->I.size(); i++) { pl->I[i] += w * contrib(k, j, i); pl->EW[i] += w * contrib(k, j, i + 5); }
+    return FDES_OK;
+}
+int fdes_plan_accumulate_from(fdes_plan* d, fdes_plan* s)
+{
+    if (d->cur_k != s->cur_k) return FDES_EINVAL; // the peer must still hold the same measurement
+    for (size_t i = 0; i < d->I.size(); i++) { d->I[i] += s->I[i]; if (d->want_ew) d->EW[i] += s->EW[i]; }
+    return FDES_OK;
+}
+int fdes_plan_get_exitwave(fdes_plan* pl, float* ew) { std::memcpy(ew, pl->EW.data(), sizeof(float) * pl->EW.size()); return FDES_OK; }
+int fdes_plan_end_measurement(fdes_plan* pl, int k)
+{
+    const size_t img = (size_t)pl->n1 * pl->n2;
+    for (size_t i = 0; i < img; i++) pl->J[(size_t)k * img + i] = pl->I[2 * (i % pl->m12)];
+    return FDES_OK;
+}
+int fdes_plan_get_images(fdes_plan* pl, float* out) { std::memcpy(out, pl->J.data(), sizeof(float) * pl->J.size()); return FDES_OK; }
+int fdes_plan_original_slices(const fdes_plan* pl) { return pl->m3; }
+int fdes_plan_potential(fdes_plan* pl, int lo, int hi, float* pot)
+{
+    for (int s = lo; s < hi; s++)
+        for (size_t i = 0; i < 2 * pl->m12; i++) pot[(size_t)(s - lo) * 2 * pl->m12 + i] = (float)s + 0.001f * (float)(i % 7);
+    return FDES_OK;
+}
+}
+
+static int run_case(int ngpu, int n3, int count, bool fail_one)
+{
+    fdes_params p;
+    std::memset(&p, 0, sizeof p);
+    p.n1 = 6; p.n2 = 5; p.m1 = 8; p.m2 = 8; p.n3 = n3; p.m3 = 7; p.frPh = count > 1 ? count : 0;
+    fdes_atoms a = {0, nullptr, nullptr, nullptr, nullptr};
+    std::vector<int> dev((size_t)ngpu);
+    for (int r = 0; r < ngpu; r++) dev[(size_t)r] = r;
+    if (fail_one) dev[(size_t)(ngpu / 2)] = 99;
+    const size_t m12 = 64, img = 30;
+    std::vector<float> image(img * (size_t)n3, -1.f), pot(2 * m12 * 7, -1.f), ew(2 * m12 * (size_t)n3, -1.f);
+    const int rc = fdes_build_measurements_multi(ngpu, dev.data(), &p, &a, image.data(), pot.data(), ew.data());
+    if (fail_one) return rc == FDES_OK ? 1 : 0; // must report the failure and must not hang
+    if (rc != FDES_OK) return 1;
+    const int cnt = count > 1 ? count : 1;
+    const float w = 1.f / (float)cnt;
+    int bad = 0;
+    for (int k = 0; k < n3; k++)
+        for (size_t i = 0; i < img; i++) {
+            double s = 0;
+            for (int j = 0; j < cnt; j++) s += (double)w * contrib(k, j, 2 * (i % m12));
+            if (std::abs((double)image[(size_t)k * img + i] - s) > 1e-5) bad++;
+        }
+    for (int k = 0; k < n3; k++)
+        for (size_t i = 0; i < 2 * m12; i++) {
+            double s = 0;
+            for (int j = 0; j < cnt; j++) s += (double)w * contrib(k, j, i + 5);
+            if (std::abs((double)ew[(size_t)k * 2 * m12 + i] - s) > 1e-5) bad++;
+        }
+    for (int s = 0; s < 7; s++)
+        for (size_t i = 0; i < 2 * m12; i++)
+            if (pot[(size_t)s * 2 * m12 + i] != (float)s + 0.001f * (float)(i % 7)) bad++;
+    return bad;
+}
+
+int main()
+{
+    int bad = 0;
+    const int cases[][3] = {{2, 1, 8}, {3, 2, 4}, {4, 5, 3}, {8, 1, 32}, {8, 64, 8}, {5, 3, 1}, {8, 3, 2}, {7, 1, 3}};
+    for (auto& c : cases) {
+        const int b = run_case(c[0], c[1], c[2], false);
+        std::printf("gpus %d measurements %d configurations %d: %s\n", c[0], c[1], c[2], b ? "MISMATCH" : "ok");
+        bad += b;
+    }
+    bad += run_case(4, 2, 4, true);
+    std::printf(bad ? "FAILED\n" : "all ok\n");
+    return bad ? 1 : 0;
+}

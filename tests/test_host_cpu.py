@@ -508,3 +508,34 @@ def test_shipped_cnf_files_parse(name):
         assert ae.n == 309 and (he.c.m1, he.c.m3, he.c.n3) == (c.m1, c.m3, c.n3)
         assert np.allclose(ae.xyz, at.xyz, rtol=0, atol=1e-16) and abs(he.c.pD - c.pD) < 1e-6
         assert np.allclose(he.tiltspec[:50], hp.tiltspec[:50], atol=1e-7)
+
+
+def _build_and_run(tmp_path, name, sources, flags, args=(), env=None):
+    exe = str(tmp_path / name)
+    cmd = ["g++", "-std=c++17", "-O1", "-g", *flags, "-I", os.path.join(ROOT, "include"), "-o", exe,
+           *[os.path.join(ROOT, s) for s in sources], "-ldl", "-lpthread"]
+    subprocess.check_call(cmd)
+    return subprocess.run([exe, *args], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+
+
+def test_multi_gpu_driver_under_thread_sanitizer(tmp_path):
+    """fdes_amd/csrc/multi.cpp (host threads, barriers, partition, ownership, failure of one worker) linked against stub
+    plans that keep their sums in unlocked host memory, under ThreadSanitizer: any pair of calls the driver's barriers
+    do not order is a reported race; the images / exit waves / potential must equal the serial sums."""
+    r = _build_and_run(tmp_path, "multi_tsan", ["tests/host_cpp/multi_tsan.cpp", "fdes_amd/csrc/multi.cpp"], ["-fsanitize=thread"],
+                       env={"TSAN_OPTIONS": "halt_on_error=1 exitcode=66"})
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0 and "all ok" in r.stdout and "ThreadSanitizer" not in r.stderr
+
+
+def test_host_parsers_under_address_sanitizer(tmp_path):
+    """The .cnf / .qsc / .cfg / .emd readers and writers (no GPU code) under AddressSanitizer + UBSan: the shipped inputs
+    in every reader mode, write -> read round trips, and damaged inputs (truncated, over-long lines, missing values,
+    garbage)."""
+    r = _build_and_run(tmp_path, "parsers_asan",
+                       ["tests/host_cpp/parsers_asan.cpp", "fdes_amd/csrc/cnf.cpp", "fdes_amd/csrc/qsc.cpp", "fdes_amd/csrc/emd.cpp",
+                        "fdes_amd/csrc/params.cpp"], ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"],
+                       args=[os.path.join(ROOT, "tests", "golden"), str(tmp_path)], env={"ASAN_OPTIONS": "detect_leaks=1"})
+    print(r.stdout[-1500:], r.stderr[-3000:])
+    assert r.returncode == 0 and "all ok" in r.stdout
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
