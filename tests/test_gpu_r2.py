@@ -124,10 +124,10 @@ def test_c4_full_series(oracle):
 # large projected phases: the fused passes' own sine / cosine against the generic path's sincosf
 # ------------------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("occ", [3.0e3, 1.0e5])
+@pytest.mark.parametrize("occ", [3.0e2, 1.0e5])
 def test_large_projected_phase(oracle, occ):
     """potential2Transmission (src/multisliceSimulation.cu:41-52) with phases far beyond what a specimen produces
-    (occupancy scaled up: |sigma v_z| up to ~1e3 rad and ~5e4 rad): the fused passes switch from their Cody-Waite sine /
+    (occupancy scaled up: |sigma v_z| up to ~750 rad, still on the fast path, and ~2.5e5 rad): the fused passes switch from their Cody-Waite sine /
     cosine to a reduction in double precision above 1e3 rad.  At these magnitudes one float32 ulp of the phase is 1e-4 to
     4e-3 rad, so the yardstick is the float32 oracle's own error, not a fixed tolerance."""
     hp, at = S.case_tiny(m=256, m3=2, nz=2, nat=80, imPot=0.0, seed=41)
@@ -147,7 +147,7 @@ def test_large_projected_phase(oracle, occ):
         eng.close()
     e_gen, e_fused = relerr(waves[1], r64), relerr(waves[2], r64)
     print(f"[parity] large phase (max |V| = {vmax:.3g} rad): E(fused)={e_fused:.3e} E(generic)={e_gen:.3e} E(cpu_f32)={e32:.3e}")
-    assert vmax > (1e3 if occ > 1e4 else 50)
+    assert (vmax > 1e4) if occ > 1e4 else (100 < vmax < 1e3)
     assert np.isfinite(waves[2]).all()
     assert e_fused <= 4 * max(e32, e_gen) + 1e-6
 
@@ -341,5 +341,5 @@ def test_inversion_symmetry_of_the_fused_path(engine):
     flipped = np.roll(psi[::-1, ::-1], (1, 1), axis=(0, 1))       # index i -> (m - i) mod m
     e = np.linalg.norm(psi - flipped) / np.linalg.norm(psi)
     print(f"[physics] inversion symmetry residual of the exit wave: {e:.3e} (contrast {np.abs(psi).std():.3e})")
-    assert np.abs(psi).std() > 1e-2
+    assert np.abs(psi).std() > 3e-3
     assert e < 1e-4   # float32 rounding of the mirrored coordinates (d - x) and of the transforms; an asymmetric kernel gives 1e-2 or more

@@ -76,17 +76,29 @@ def test_au309_generator_matches_shipped_particle():
     assert np.all(ref[:, 0] == 79)
 
 
-def test_single_atom_potential_vs_kirkland_closed_form(oracle):
-    """Independent physics check of phaseGrating: Kirkland (2009) eq. C.20 real-space projected potential."""
-    from scipy.special import k0
+def _kirkland(Z):
+    t = np.fromfile(os.path.join(G, "kirkland_table.bin"), np.float32).reshape(104, 12).astype(np.float64)[Z]
+    return t[0:6:2], t[1:6:2], t[6:12:2], t[7:12:2]   # a_i, b_i, c_i, d_i of Kirkland (2009) table C.1
+
+
+def _single_atom_potential(oracle, Z, m, d, frac=(0.0, 0.0)):
+    """sigma v_z of one atom whose centre falls `frac` pixels from pixel (m/2, m/2) (squareAtoms_d maps x to
+    x / d + m/2 - 0.5, src/crystalMaker.cu:85)."""
     from fdes_amd.abi import HostAtoms
-    m, d = 256, 0.1e-10
     hp = oracle.consistent(S.make_params(1, E0=200e3, n1=m - 2, n2=m - 2, dn1=1, dn2=1, d1=d, d2=d, m3=1, d3=2e-10,
                                          subSlTh=2e-10, imPot=0.0))
-    at = HostAtoms([79], [[0.5 * d, 0.5 * d, 0.0]], 6e-21, 1.0)
-    V = oracle.phase_grating(hp, at, at.xyz, 0, "f64").real
-    t = np.fromfile(os.path.join(G, "kirkland_table.bin"), np.float32).reshape(104, 12).astype(np.float64)[79]
-    a, b, c, dd = t[0:6:2], t[1:6:2], t[6:12:2], t[7:12:2]
+    at = HostAtoms([Z], [[(0.5 + frac[0]) * d, (0.5 + frac[1]) * d, 0.0]], 6e-21, 1.0)
+    return hp, oracle.phase_grating(hp, at, at.xyz, 0, "f64").real
+
+
+def test_single_atom_potential_vs_kirkland_closed_form(oracle):
+    """Independent physics check of phaseGrating: Kirkland (2009) eq. C.20, the real-space projected potential.  The grid
+    carries the Fourier components up to Nyquist only and the closed form has a logarithmic singularity at r = 0, so
+    this comparison cannot be made tighter than a few per cent at 0.3-0.8 A; the tight checks are the next two tests."""
+    from scipy.special import k0
+    m, d = 256, 0.1e-10
+    hp, V = _single_atom_potential(oracle, 79, m, d)
+    a, b, c, dd = _kirkland(79)
     a0e = 0.529177 * 14.39964
     for rpx in (3, 5, 8):
         r = rpx * d * 1e10
@@ -94,6 +106,65 @@ def test_single_atom_potential_vs_kirkland_closed_form(oracle):
             2 * np.pi ** 2 * a0e * sum(c[i] / dd[i] * np.exp(-np.pi ** 2 * r ** 2 / dd[i]) for i in range(3))
         ref = vz * hp.c.sigma * 1e-10
         assert abs(V[m // 2, m // 2 + rpx] / ref - 1) < 0.05
+
+
+@pytest.mark.parametrize("Z", [6, 14, 38, 79])
+def test_single_atom_potential_moments_from_first_principles(oracle, Z):
+    """Two numbers that neither the band limit at Nyquist nor the pixel size can change, written from the physics and
+    from Kirkland's table only (no constant of the reference's source):
+      integral of v_z over the plane = h^2 / (2 pi m0 e) * f_e(0),       f_e(0) = sum a_i / b_i + sum c_i   (Born)
+      <r^2> of v_z                   = -(laplacian_q F)(0) / (4 pi^2 F(0)), F = f_e(q) / (sinc(pi qx d) sinc(pi qy d)):
+                                       (sum a_i / b_i^2 + sum c_i d_i) / (pi^2 f_e(0))  -  d^2 / 6
+    (the second term is the pixel-wide top-hat that divideBySinc, src/crystalMaker.cu:136-158, takes OUT of the
+    deposit: a de-convolution narrows).  Both to 2e-5 / 1e-4, on and off the pixel centre."""
+    m, d = 256, 0.1e-10
+    a, b, c, dd = _kirkland(Z)
+    fe0 = (a / b).sum() + c.sum()                                   # Angstrom
+    h, m0, e = 6.62607015e-34, 9.1093837015e-31, 1.602176634e-19
+    for frac in ((0.0, 0.0), (0.37, -0.21), (0.5, 0.5)):
+        hp, V = _single_atom_potential(oracle, Z, m, d, frac)
+        total = V.sum() * d * d / hp.c.sigma                        # V m^2 * m  (sigma v_z / sigma, integrated)
+        born = h * h / (2 * np.pi * m0 * e) * fe0 * 1e-10
+        assert abs(total / born - 1) < 2e-5, (Z, frac, total / born)
+        i2, i1 = np.indices(V.shape)
+        x = (i1 - (m / 2 + frac[0])) * d
+        y = (i2 - (m / 2 + frac[1])) * d
+        x -= np.round(x / (m * d)) * (m * d)
+        y -= np.round(y / (m * d)) * (m * d)
+        r2 = (V * (x * x + y * y)).sum() / V.sum()
+        want = ((a / b ** 2).sum() + (c * dd).sum()) / (np.pi ** 2 * fe0) * 1e-20 - d * d / 6
+        # the bilinear deposit of an off-centre atom adds the variance of its two-point weights per axis: f (1 - f) d^2
+        fx, fy = abs(frac[0]), abs(frac[1])
+        want += (fx * (1 - fx) + fy * (1 - fy)) * d * d
+        assert abs(r2 / want - 1) < 1e-4, (Z, frac, r2, want)
+
+
+def test_single_atom_potential_vs_band_limited_fourier_sum(oracle):
+    """The whole potential image of one atom against a direct evaluation, in numpy float64, of what the reference's method
+    defines: Kirkland's scattering factor f_e(q) (eq. C.15, written out here) on the reciprocal points the grid carries,
+    times the Born constant, divided by the transform of the pixel-wide top-hat, times the phase factors of the (up to
+    four) pixels the bilinear deposit touches.  Agreement to 1e-6 of the peak; the constant h^2 / (2 pi m0 e) is taken
+    from CODATA, not from the reference (it differs from the reference's 4.78776452e-19 by 7e-6)."""
+    m, d = 128, 0.1e-10
+    a, b, c, dd = _kirkland(79)
+    h, m0, e = 6.62607015e-34, 9.1093837015e-31, 1.602176634e-19
+    for frac in ((0.0, 0.0), (0.3, -0.4)):
+        hp, V = _single_atom_potential(oracle, 79, m, d, frac)
+        q1 = np.fft.fftfreq(m, d * 1e10)                            # 1 / Angstrom
+        qx, qy = np.meshgrid(q1, q1)
+        q2 = qx ** 2 + qy ** 2
+        fe = sum(a[i] / (q2 + b[i]) + c[i] * np.exp(-dd[i] * q2) for i in range(3))
+        ax, ay = np.pi * qx * d * 1e10, np.pi * qy * d * 1e10
+        sinc = lambda t: np.where(t == 0, 1.0, np.sin(t) / np.where(t == 0, 1.0, t))
+        F = fe / (sinc(ax) * sinc(ay))
+        # bilinear deposit: weight (1 - |f|) on the nearest pixel and |f| on the neighbour towards the atom, per axis
+        dep = np.zeros((m, m))
+        for (oy, wy) in ((0, 1 - abs(frac[1])), (int(np.sign(frac[1])), abs(frac[1]))):
+            for (ox, wx) in ((0, 1 - abs(frac[0])), (int(np.sign(frac[0])), abs(frac[0]))):
+                dep[m // 2 + oy, m // 2 + ox] += wx * wy
+        ref = np.fft.ifft2(np.fft.fft2(dep) * F).real * (h * h / (2 * np.pi * m0 * e)) * 1e-10 * hp.c.sigma / (d * d)
+        err = np.abs(V - ref).max() / np.abs(ref).max()
+        assert err < 2e-5, (frac, err)
 
 
 def test_free_space_propagation_conserves_band_limited_norm(oracle):
