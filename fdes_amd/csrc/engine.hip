@@ -41,7 +41,8 @@ struct fdes_ctx {
     int bench_band = 0;   // fdes_bench_pass only
     int bench_alt = -1;   // fdes_bench_pass only: >= 0: odd streams run pass (alt / 10000, alt / 100 % 100, alt % 100) instead
     int bench_tall = 1;   // fdes_bench_pass only: rows = bench_tall * n (emulates a batch of configurations in one launch)
-    float2* share_PT = nullptr; // lane contexts: tables owned by the parent plan
+    int bench_pitch = 0;  // fdes_bench_pass only: rows of every scratch grid are padded by this many elements
+    float2* share_PT = nullptr; // lane contexts: tables owned by the parent plan (PT: separable propagator, px[m1] | py[m2])
     float* share_GT = nullptr;
     int band_skip = 1;    // do not move / transform the rows and columns the 2/3 band limit zeroes anyway
     int skip_empty = 1;   // slices without atoms: t = 1, only the Fresnel step is applied (fused loop)
@@ -105,8 +106,8 @@ struct fdes_plan {
     float2 *A = nullptr, *B = nullptr, *C = nullptr, *C2 = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
     float* GT = nullptr;
     bool tables_shared = false; // PT / GT belong to the parent plan (lanes)
-    // P^n tables for runs of n empty slices (skip_empty): built on first use on this plan's stream, least recently used
-    // of 6 replaced
+    // P^n tables (separable: m1 + m2 complex numbers) for runs of n empty slices (skip_empty): built on first use on this
+    // plan's stream, least recently used of 16 replaced
     struct PowTab { int n; float2* tab; uint64_t used; };
     std::vector<PowTab> pow_tabs;
     uint64_t pow_tick = 0;
@@ -338,19 +339,20 @@ int fused_potential_pair(fdes_plan* pl, int s0)
     return FDES_OK;
 }
 
-// table of P^n (n >= 2) for a run of empty slices
+// separable table of P^n (n >= 2) for a run of empty slices: px^n[m1] | py^n[m2]
 int propagator_pow(fdes_plan* pl, int n, float2** out)
 {
     fdes_ctx* c = pl->ctx;
+    const size_t len = (size_t)pl->p.m1 + (size_t)pl->p.m2;
     if (pl->capture_pow) {
         // inside a graph capture the table belongs to that graph: its build kernel is one of the nodes, so every replay
         // refreshes it and nothing depends on what other patterns did to a shared cache in between
         for (auto& e : *pl->capture_pow)
             if (e.first == n) { *out = e.second; return FDES_OK; }
         float2* t = nullptr;
-        RC(dmalloc(c, &t, pl->m12));
+        RC(dmalloc(c, &t, len));
         pl->capture_pow->push_back({n, t});
-        HIPCHK(c, k_build_propagator_pow(t, pl->kp, 1, n, c->stream));
+        HIPCHK(c, k_build_propagator_1d(t, t + pl->p.m1, pl->kp, n, c->stream));
         *out = t;
         return FDES_OK;
     }
@@ -358,15 +360,15 @@ int propagator_pow(fdes_plan* pl, int n, float2** out)
         if (e.n == n) { e.used = ++pl->pow_tick; *out = e.tab; return FDES_OK; }
     std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc
     float2* tab = nullptr;
-    if (pl->pow_tabs.size() >= 6) {
+    if (pl->pow_tabs.size() >= 16) {
         size_t lru = 0;
         for (size_t i = 1; i < pl->pow_tabs.size(); i++) if (pl->pow_tabs[i].used < pl->pow_tabs[lru].used) lru = i;
         tab = pl->pow_tabs[lru].tab; // stream order makes the overwrite safe: its last reader was enqueued earlier
         pl->pow_tabs.erase(pl->pow_tabs.begin() + (long)lru);
     } else {
-        RC(dmalloc(c, &tab, pl->m12));
+        RC(dmalloc(c, &tab, len));
     }
-    HIPCHK(c, k_build_propagator_pow(tab, pl->kp, 1, n, c->stream));
+    HIPCHK(c, k_build_propagator_1d(tab, tab + pl->p.m1, pl->kp, n, c->stream));
     pl->pow_tabs.push_back({n, tab, ++pl->pow_tick});
     *out = tab;
     return FDES_OK;
@@ -398,7 +400,7 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
         float2* ptab = pl->PT;
         if (run > 1) RC(propagator_pow(pl, run, &ptab));
         PassArgs a6 = pass_y(pl);
-        a6.in0 = pl->F; a6.ptab = ptab; a6.out = pl->PSIH;
+        a6.in0 = pl->F; a6.prow = ptab; a6.pcol = ptab + m1; a6.mindim = md; a6.out = pl->PSIH;
         a6.band = band; a6.live_rows_only = bs;
         HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
         pl->slices_skipped += run;
@@ -438,7 +440,7 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
     }
     HIPCHK(c, lds_pass(m1, XF_INV, MID_MULPSI, XF_FWD, true, a5, c->stream));
     PassArgs a6 = pass_y(pl);
-    a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->PSIH;
+    a6.in0 = pl->F; a6.prow = pl->PT; a6.pcol = pl->PT + m1; a6.mindim = md; a6.out = pl->PSIH;
     a6.band = band; a6.live_rows_only = bs;
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
     return FDES_OK;
@@ -764,6 +766,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "bench_alt")) { c->bench_alt = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_tall")) { if (value < 1 || value > 4) return FDES_EINVAL; c->bench_tall = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_band")) { c->bench_band = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "bench_pitch")) { if (value < 0 || value > 4096) return FDES_EINVAL; c->bench_pitch = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "skip_empty")) { c->skip_empty = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "lanes")) { if (value < 0 || value > 4) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
@@ -932,14 +935,14 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         PLCHK(dmalloc(c, &pl->PSIH, pl->m12));
         if (c->share_PT) { pl->PT = c->share_PT; pl->GT = c->share_GT; pl->tables_shared = true; }
         else {
-            PLCHK(dmalloc(c, &pl->PT, pl->m12));
+            PLCHK(dmalloc(c, &pl->PT, (size_t)pl->p.m1 + (size_t)pl->p.m2));
             PLCHK(dmalloc(c, &pl->GT, pl->m12 * (size_t)pl->nZ));
         }
         PLCHK(dmalloc(c, &pl->bins.rowstart, (size_t)pl->p.m3 * pl->nZ * (size_t)(pl->p.m2 + 1)));
         // dead (band-limited) rows / columns of these grids are never written again: they must read as zero
         for (float2* q : {pl->C, pl->C2, pl->E, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->m12, c->stream));
         if (!pl->tables_shared) {
-            PLHIP(k_build_propagator(pl->PT, pl->kp, 1, c->stream));
+            PLHIP(k_build_propagator_1d(pl->PT, pl->PT + pl->p.m1, pl->kp, 1, c->stream));
             for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 1, c->stream));
         }
     }
@@ -1319,7 +1322,7 @@ int fdes_plan_propagate_dev(fdes_plan* pl, void* psi_dev, const void* t_dev, int
             a5.band = band; a5.skip_dead_stores = bs;
             HIPCHK(c, lds_pass(m1, XF_NONE, MID_MULPSI, XF_FWD, true, a5, c->stream));
             PassArgs a6 = pass_y(pl);
-            a6.in0 = pl->F; a6.ptab = pl->PT; a6.out = pl->E;
+            a6.in0 = pl->F; a6.prow = pl->PT; a6.pcol = pl->PT + m1; a6.mindim = md; a6.out = pl->E;
             a6.band = band; a6.live_rows_only = bs;
             HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
             PassArgs a7 = pass_x(pl);
@@ -1368,29 +1371,39 @@ int fdes_fft2d_host(fdes_ctx* c, float* data, int m1, int m2, int inverse, int b
 int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t, int iters, int streams, double* us)
 {
     if (!c || !us || iters < 1 || streams < 1 || streams > 8 || !lds_fft_supported_len(n)) return FDES_EINVAL;
+    // passes whose operands this hook does not provide (atom records, second output grid, species loop) are refused:
+    // launching them on the scratch arguments would write through null pointers
+    if (mid == MID_ATOMS || mid == MID_GTABN) { c->err = "bench_pass: pass needs operands the hook does not provide"; return FDES_EINVAL; }
+    if (c->bench_alt >= 0 && ((c->bench_alt / 100 % 100) == MID_ATOMS || (c->bench_alt / 100 % 100) == MID_GTABN)) return FDES_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     Fft2D f;
     std::string ferr;
     if (f.create(n, n, 2, c->stream, &ferr) != 0) { f.destroy(); c->err = ferr; return FDES_EGPU; }
-    const size_t m12 = (size_t)n * n * (size_t)c->bench_tall;
+    const size_t m12 = (size_t)(n + c->bench_pitch) * (n * (size_t)c->bench_tall + (size_t)c->bench_pitch);
     std::vector<void*> bufs;
     std::vector<hipStream_t> sts;
     std::vector<PassArgs> args;
     int rc = FDES_OK;
     for (int q = 0; q < streams && rc == FDES_OK; q++) {
-        float2 *a = nullptr, *b = nullptr, *o = nullptr, *pt = nullptr;
+        float2 *a = nullptr, *b = nullptr, *o = nullptr, *o2 = nullptr, *pt = nullptr;
         float* g = nullptr;
         hipStream_t st = nullptr;
         if (hipMalloc((void**)&a, 8 * m12) != hipSuccess || hipMalloc((void**)&b, 8 * m12) != hipSuccess || hipMalloc((void**)&o, 8 * m12) != hipSuccess ||
+            (mid == MID_EXPIV_PAIR && hipMalloc((void**)&o2, 8 * m12) != hipSuccess) ||
             hipMalloc((void**)&pt, 8 * m12) != hipSuccess || hipMalloc((void**)&g, 4 * m12) != hipSuccess ||
             hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rc = FDES_ENOMEM; }
-        bufs.insert(bufs.end(), {a, b, o, pt, g});
+        bufs.insert(bufs.end(), {a, b, o, o2, pt, g});
         if (st) sts.push_back(st);
         if (rc != FDES_OK) break;
-        (void)hipMemset(a, 0, 8 * m12); (void)hipMemset(b, 0, 8 * m12); (void)hipMemset(pt, 0, 8 * m12); (void)hipMemset(g, 0, 4 * m12);
+        // random operands: zero-filled grids let the chip hold a higher clock than real data does
+        (void)k_fill_noise((float*)a, 2 * m12, 11u + q, c->stream); (void)k_fill_noise((float*)b, 2 * m12, 23u + q, c->stream);
+        (void)k_fill_noise((float*)pt, 2 * m12, 37u + q, c->stream); (void)k_fill_noise(g, m12, 41u + q, c->stream);
+        (void)hipMemsetAsync(o, 0, 8 * m12, c->stream);
+        (void)hipStreamSynchronize(c->stream);
         PassArgs A;
-        A.in0 = a; A.in1 = b; A.out = o; A.zsrc = a; A.gtab = g; A.ptab = pt; A.tw0 = f.tw0x; A.tw1 = f.tw1x; A.nrows = n * c->bench_tall;
+        A.in0 = a; A.in1 = b; A.out = o; A.out2 = o2; A.zsrc = a; A.gtab = g; A.prow = pt; A.pcol = pt + n * c->bench_tall; A.tw0 = f.tw0x; A.tw1 = f.tw1x; A.nrows = n * c->bench_tall;
         A.nspecies = 1; A.species_stride = m12; A.scale = 1.f; A.mindim = n;
+        if (c->bench_pitch) { A.pitch_in = n + c->bench_pitch; A.pitch_out = (store_t ? n * c->bench_tall : n) + c->bench_pitch; }
         A.wg = c->pass_threads == 256 ? 256 : ((c->pass_threads == 513 || c->pass_threads == 1) && n <= 2048 ? 1 : 512);
         if (c->bench_band) { // micro-benchmark of the band-limit bookkeeping: bit 0 live rows only, bit 1 dead loads, bit 2 dead stores
             A.band = n * n;
@@ -1399,6 +1412,15 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
             A.skip_dead_stores = (c->bench_band & 4) ? 1 : 0;
         }
         args.push_back(A);
+    }
+    // diagnostic build only (FDES_STAMP_FILE set, library built with -DFDES_STAMPS): the phase stamps of the LAST launch
+    // on stream 0 are written to that file as raw uint64[blocks * waves * 16]
+    unsigned long long* dbg = nullptr;
+    const size_t dbg_n = (size_t)4096 * 8 * 16;
+    const char* stamp_file = std::getenv("FDES_STAMP_FILE");
+    if (rc == FDES_OK && stamp_file && hipMalloc((void**)&dbg, dbg_n * 8) == hipSuccess) {
+        (void)hipMemset(dbg, 0, dbg_n * 8);
+        args[0].dbg = dbg;
     }
     if (rc == FDES_OK) {
         hipError_t e = hipSuccess;
@@ -1415,6 +1437,13 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
         auto t1 = std::chrono::steady_clock::now();
         if (e == hipSuccess) *us = std::chrono::duration<double, std::micro>(t1 - t0).count() / ((double)iters * streams);
         else { c->err = std::string("bench_pass: ") + hipGetErrorString(e); rc = FDES_EGPU; }
+    }
+    if (dbg) {
+        std::vector<unsigned long long> h(dbg_n);
+        if (hipMemcpy(h.data(), dbg, dbg_n * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* fp = std::fopen(stamp_file, "wb")) { std::fwrite(h.data(), 8, dbg_n, fp); std::fclose(fp); }
+        }
+        (void)hipFree(dbg);
     }
     for (void* q : bufs) if (q) (void)hipFree(q);
     for (hipStream_t st : sts) (void)hipStreamDestroy(st);

@@ -20,7 +20,8 @@ enum MidKind {
     MID_EXPIV = 3,  // v -> exp(-v.y) (cos v.x, sin v.x)               (potential2Transmission)
     MID_MASK = 4,   // radial 2/3 band limit * scale                     (zeroHighFreq + Csscal)
     MID_MULPSI = 5, // (row of in0) (x) (row of in1), both inverse transformed first (multiplyElementwise)
-    MID_PTAB = 6,   // spectrum (x) P[row][col]                          (multiplyElementwise with frProp)
+    MID_PTAB = 6,   // spectrum (x) P(row, col) = prow[row] pcol[col] inside the band limit, 0 outside
+                    //                                                   (multiplyElementwise with frProp)
     MID_SCALE = 7,  // * scale
     MID_GTABN = 8,  // MID_GTAB with a species loop (nspecies > 1)
     MID_ATOMS = 9,  // source rows are built from the sorted atom records (re: slice q0, im: slice q1), no grid read
@@ -36,10 +37,17 @@ struct PassArgs {
     float2* out2 = nullptr;      // MID_EXPIV_PAIR: second output grid
     float2* zsrc = nullptr;      // MID_ZSRC: rows to clear (== in0)
     const float* gtab = nullptr; // MID_GTAB: [species][row][col]
-    const float2* ptab = nullptr;
+    // Fresnel propagator, separable: P(k_row, k_col) = prow[row] * pcol[col] inside the radial band limit (prow carries
+    // 1 / (m1 m2)); two 1-D tables instead of a grid (needs mindim)
+    const float2* prow = nullptr;
+    const float2* pcol = nullptr;
     const float2* tw0 = nullptr; // twiddles of this row length
     const float2* tw1 = nullptr;
     int nrows = 0;               // rows of the input grid (= leading dimension of a transposed output)
+    // Row pitches in elements (0: dense).  pitch_in: distance between input rows (in0, in1, ptab, gtab, zsrc);
+    // pitch_out: distance between output rows (natural store: default n; transposed store: default nrows).  A pitch
+    // that is not a power of two spreads the 2^k-strided segments of a transposed store over the memory channels.
+    int pitch_in = 0, pitch_out = 0;
     int nspecies = 1;
     size_t species_stride = 0;   // elements between species grids (in0 and gtab)
     float scale = 1.f;
@@ -56,6 +64,8 @@ struct PassArgs {
     const void* recs = nullptr;  // AtomRec[] sorted by (slice, species, row)
     const int* rowstart = nullptr; // [q][nrows + 1]
     int q0 = -1, q1 = -1;        // (slice * nZ + species) deposited into the real / imaginary component (-1: none)
+    // diagnostic builds (-DFDES_STAMPS): per wave, 16 shader-clock stamps of the pass's phases (tools/stamps.py)
+    unsigned long long* dbg = nullptr;
     // host side only: when set, the dispatch is bracketed by these two events through hipExtLaunchKernelGGL, whose
     // timestamps come from the dispatch packet itself (kernel begin / end, what a profiler reports) rather than from
     // marker packets before and after it

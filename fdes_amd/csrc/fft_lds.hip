@@ -373,7 +373,16 @@ __device__ __forceinline__ void xform(float2 (&a)[WGeo<WG>::NRV][16], float2* ld
 // two-operand passes need the registers of two waves per SIMD
 constexpr int pass_waves(int mid) { return (mid == MID_MULPSI || mid == MID_GTABN) ? 2 : FDES_WAVES; }
 #ifndef FDES_PAIR_TWR
-#define FDES_PAIR_TWR 1 // register twiddles in the two-slice transmission pass (16 spilled registers at 2048, still +4 % over table fetches)
+#define FDES_PAIR_TWR 0 // register twiddles in the two-slice transmission pass: 16 spilled registers at 2048; measured 38.3 / 30.7 us (one / two streams) against 37.2 / 28.7 us with fetched twiddles
+#endif
+#ifndef FDES_NO_TWR
+#define FDES_NO_TWR 0 // A/B switch: 1 = every pass fetches its stage twiddles at the point of use
+#endif
+#ifndef FDES_PTAB_TWR
+#define FDES_PTAB_TWR 0 // register twiddles in the propagator pass: 13 spilled registers at 2048, measured slower (21.9 vs 19.5 us)
+#endif
+#ifndef FDES_PSEP_LATE
+#define FDES_PSEP_LATE 1
 #endif
 #ifndef FDES_P5_PREFETCH
 #define FDES_P5_PREFETCH 0 // requesting the second operand with the first: measured, no gain (A/B 12.1k vs 12.1k), 14 more VGPRs
@@ -405,13 +414,33 @@ __device__ __forceinline__ void load_rows(float2 (&a)[WGeo<WG>::NRV][16], const 
         }
 }
 
+// In-kernel stamps (diagnostic build only, -DFDES_STAMPS; no stamp executes in the product): lane 0 of every wave
+// writes the shader clock at phase boundaries to A.dbg[(block * waves + wave) * 16 + slot]; WAITV drains the wave's
+// vector-memory queue first so that the stamp separates "requested" from "landed".
+#ifdef FDES_STAMPS
+#define STAMP(slot, WAITV)                                                                                               \
+    do {                                                                                                                 \
+        if (A.dbg) {                                                                                                     \
+            if (WAITV) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            const unsigned long long t_ = (slot) == 15 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+            if ((threadIdx.x & 63) == 0) A.dbg[((size_t)blockIdx.x * (WGeo<WG>::THR / 64) + threadIdx.x / 64) * 16 + (slot)] = t_; \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+        }                                                                                                                \
+    } while (0)
+#else
+#define STAMP(slot, WAITV) do { } while (0)
+#endif
+
 template <int N, int WG, int PRE, int MID, int POST, bool STORE_T>
 __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) void k_pass(PassArgs A)
 {
     using G_ = Geo<N, WG>;
     constexpr int T = G_::T, R = G_::R, RH = G_::RH;
     extern __shared__ float2 lds[];
-    constexpr bool TWR = (pass_waves(MID) == 2) && (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && MID != MID_PTAB && MID != MID_GTABN && (MID != MID_EXPIV_PAIR || (FDES_PAIR_TWR && N <= 2048)));
+    STAMP(0, false);
+    STAMP(15, false); // wall clock (100 MHz) of the same instant
+    constexpr bool TWR = !FDES_NO_TWR && (pass_waves(MID) == 2) && (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && (MID != MID_PTAB || FDES_PTAB_TWR) && MID != MID_GTABN && (MID != MID_EXPIV_PAIR || (FDES_PAIR_TWR && N <= 2048)));
     Tw tw;
     tw.g0 = reinterpret_cast<const float2*>(A.tw0);
     tw.g1 = reinterpret_cast<const float2*>(A.tw1);
@@ -452,18 +481,19 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
         if (bg >= g_lo) bg = g_hi + (bg - g_lo);
     }
     const int row0 = bg * R;
-    // uniform row-group base (scalar registers) + 32-bit per-thread element offsets (< R * N = 16384)
-    const size_t gbase = (size_t)row0 * N;
+    // uniform row-group base (scalar registers) + 32-bit per-thread element offsets (< R * pitch)
+    const unsigned pin = A.pitch_in ? (unsigned)A.pitch_in : (unsigned)N;
+    const unsigned ldt = A.pitch_out ? (unsigned)A.pitch_out : (unsigned)A.nrows; // leading dimension of a transposed output
+    const size_t gbase = (size_t)row0 * pin;
     unsigned rbase[WGeo<WG>::NRV];
     int grow[WGeo<WG>::NRV];
 #pragma unroll
     for (int h = 0; h < WGeo<WG>::NRV; h++) {
         grow[h] = row0 + r + h * RH;
-        rbase[h] = (unsigned)((r + h * RH) * N);
+        rbase[h] = (unsigned)(r + h * RH) * pin;
     }
     const float2* __restrict__ in0 = A.in0 ? reinterpret_cast<const float2*>(A.in0) + gbase : nullptr;
     const float2* __restrict__ in1 = A.in1 ? reinterpret_cast<const float2*>(A.in1) + gbase : nullptr;
-    const float2* __restrict__ ptab = A.ptab ? reinterpret_cast<const float2*>(A.ptab) + gbase : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
     float2* __restrict__ zsrc = A.zsrc ? reinterpret_cast<float2*>(A.zsrc) + gbase : nullptr;
     if constexpr (MID == MID_ATOMS) A.out += (size_t)blockIdx.y * A.species_stride; // one launch covers every species
@@ -523,7 +553,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
 #pragma unroll
                     for (int it = 0; it < WGeo<WG>::NRV * 16; it++) {
                         const int e = it * WGeo<WG>::THR + tid;
-                        (reinterpret_cast<float2*>(A.out) + row0)[(unsigned)(e / R) * (unsigned)A.nrows + (unsigned)(e & (R - 1))] = make_float2(0.f, 0.f);
+                        (reinterpret_cast<float2*>(A.out) + row0)[(unsigned)(e / R) * ldt + (unsigned)(e & (R - 1))] = make_float2(0.f, 0.f);
                     }
                 }
                 return;
@@ -576,6 +606,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
         } else {
         load_rows<N, WG>(a, in0, rbase, t, A.skip_dead_loads != 0);
         }
+        STAMP(1, false);
         if constexpr (MID == MID_ZSRC) {
 #pragma unroll
             for (int h = 0; h < WGeo<WG>::NRV; h++)
@@ -584,14 +615,20 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
         }
         // table operands are requested together with the rows (one burst of independent loads) and stay in
         // registers across the first transform; left at their point of use the compiler issues them one by one
-        float2 pv[(MID == MID_PTAB) ? WGeo<WG>::NRV : 1][16];
+        float2 pv[(MID == MID_PTAB) ? 1 : 1][16]; // column factors of the propagator: the same for every row of the thread
+        float2 pr[WGeo<WG>::NRV];                  // row factors
         float gvv[(MID == MID_GTAB) ? WGeo<WG>::NRV : 1][16];
-        if constexpr (MID == MID_PTAB) {
+        auto load_prop = [&]() {
+            const float2* __restrict__ pcol = reinterpret_cast<const float2*>(A.pcol);
+            const float2* __restrict__ prow = reinterpret_cast<const float2*>(A.prow);
 #pragma unroll
-            for (int h = 0; h < WGeo<WG>::NRV; h++)
+            for (int l = 0; l < 16; l++) pv[0][l] = pcol[t + T * l];
 #pragma unroll
-                for (int l = 0; l < 16; l++) pv[h][l] = ptab[rbase[h] + t + T * l];
-        }
+            for (int h = 0; h < WGeo<WG>::NRV; h++) pr[h] = prow[grow[h]];
+        };
+        // the 1-D propagator tables sit in the caches: requested after the first transform (FDES_PSEP_LATE) they do not
+        // hold 36 registers across it, requested with the rows their latency is hidden
+        if constexpr (MID == MID_PTAB && !FDES_PSEP_LATE) load_prop();
         if constexpr (MID == MID_GTAB) {
 #pragma unroll
             for (int h = 0; h < WGeo<WG>::NRV; h++)
@@ -600,7 +637,9 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
         }
         // second operand of the product: requested with the first so that its HBM round trip overlaps the first transform
         if constexpr (MID == MID_MULPSI && FDES_P5_PREFETCH) load_rows<N, WG>(b, in1, rbase, t, A.skip_dead_loads != 0);
+        STAMP(2, true);  // first operand (and tables) landed
         xform<N, WG, PRE, false, TWR>(a, lds, r, t, tw, gs);
+        STAMP(3, false); // first transform done
         if constexpr (MID == MID_EXPIV) {
             expiv_all(a, [&](float2 v, auto wide) {
                 const float e = __expf(-v.y);
@@ -667,13 +706,33 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
                     a[h][l] = make_float2(a[h][l].x * gv, a[h][l].y * gv);
                 }
         } else if constexpr (MID == MID_PTAB) {
+            if constexpr (FDES_PSEP_LATE) load_prop();
+            // psi-hat * P with P(kx, ky) = exp(-i pi lambda d3 kx^2) exp(-i pi lambda d3 ky^2) / (m1 m2) inside the radial 2/3
+            // band limit (fresnelPropagatorDevice + zeroHighFreq, src/multisliceSimulation.cu:225-274, 594-603): the phase
+            // is a sum of a row term and a column term, so two 1-D tables replace the m1 x m2 grid (a third of this pass's
+            // memory traffic); the mask is the integer predicate of MID_MASK.
+            const int md2 = A.mindim * A.mindim;
 #pragma unroll
-            for (int h = 0; h < WGeo<WG>::NRV; h++)
+            for (int h = 0; h < WGeo<WG>::NRV; h++) {
+                const int i2 = iwc(grow[h], A.nrows);
+                const int q = md2 - 9 * i2 * i2;
+                int Lr = (int)(sqrtf((float)(q > 0 ? q : 0)) * (1.0f / 3.0f));
+                Lr += (9 * (Lr + 1) * (Lr + 1) <= q) ? 1 : 0;
+                Lr -= (9 * Lr * Lr > q) ? 1 : 0; // q < 0: Lr = -1, nothing is live
+                const int tlo = Lr, thi = N - Lr;
 #pragma unroll
-                for (int l = 0; l < 16; l++) a[h][l] = cmul3(a[h][l], pv[h][l]);
+                for (int l = 0; l < 16; l++) {
+                    const bool live = (l < 8) ? (t <= tlo - T * l) : (t >= thi - T * l);
+                    const float2 w = cmul3(pr[h], pv[0][l]);
+                    const float2 v = cmul3(a[h][l], w);
+                    a[h][l] = live ? v : make_float2(0.f, 0.f);
+                }
+            }
         } else if constexpr (MID == MID_MULPSI) {
             if constexpr (!FDES_P5_PREFETCH) load_rows<N, WG>(b, in1, rbase, t, A.skip_dead_loads != 0);
+            STAMP(4, true);  // second operand landed
             xform<N, WG, PRE, true, TWR>(b, lds, r, t, tw, gs);
+            STAMP(5, false); // second transform done
 #pragma unroll
             for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
@@ -682,11 +741,12 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
     }
     auto store_rows = [&](float2 (&v)[WGeo<WG>::NRV][16], float2* outp) {
         if constexpr (!STORE_T) {
-            float2* __restrict__ on = outp + gbase;
+            const unsigned pout = A.pitch_out ? (unsigned)A.pitch_out : (unsigned)N;
+            float2* __restrict__ on = outp + (size_t)row0 * pout;
 #pragma unroll
             for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
-                for (int l = 0; l < 16; l++) on[rbase[h] + t + T * l] = v[h][l];
+                for (int l = 0; l < 16; l++) on[(unsigned)(r + h * RH) * pout + t + T * l] = v[h][l];
         } else {
             // stage the R x N tile as [c][r] (swizzled) and write R contiguous elements per output row
             __syncthreads();
@@ -700,8 +760,9 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
                 }
             }
             __syncthreads();
+            STAMP(10, false); // transposed tile staged
             float2* __restrict__ dst = outp + row0; // transposed grid: N rows of length nrows
-            const unsigned ld = (unsigned)A.nrows;
+            const unsigned ld = ldt;
             const int rr = tid & (R - 1), c0 = tid / R; // WG is a multiple of R: rr is the same in every iteration
 #pragma unroll
             for (int it = 0; it < WGeo<WG>::NRV * 16; it++) {
@@ -715,8 +776,12 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
             }
         }
     };
+    STAMP(6, false); // point-wise work done
     xform<N, WG, POST, (PRE != XF_NONE), TWR>(a, lds, r, t, tw, gs);
+    STAMP(7, false); // last transform done
     store_rows(a, reinterpret_cast<float2*>(A.out));
+    STAMP(8, false); // stores issued
+    STAMP(9, true);  // stores drained
     if constexpr (MID == MID_EXPIV_PAIR) {
 #pragma unroll
         for (int h = 0; h < WGeo<WG>::NRV; h++)

@@ -21,6 +21,7 @@ struct Kirk { float a0, b0, a1, b1, a2, b2, c0, d0, c1, d1, c2, d2; };
 Kirk kirkland_params(int Z);
 
 hipError_t k_fill(float2* f, size_t n, float re, float im, hipStream_t st);
+hipError_t k_fill_noise(float* f, size_t n, unsigned seed, hipStream_t st);
 hipError_t k_scale(float2* f, size_t n, float alpha, hipStream_t st);
 hipError_t k_axpy(float2* y, const float2* x, size_t n, float alpha, hipStream_t st);
 // Vhat = (first ? 0 : Vhat) + Dhat * g_Z(q) ; Dhat = 0   (projectedPotential_d * divideBySinc * multiplyWith...)
@@ -32,7 +33,8 @@ hipError_t k_pick_potential(float2* V, const float2* W, size_t n, int comp, floa
 hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st);
 hipError_t k_mul(float2* dst, const float2* f0, const float2* f1, size_t n, hipStream_t st); // dst = f0 (x) f1, 3-mult
 hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_t st);
-hipError_t k_build_propagator_pow(float2* P, const KP& p, int transposed, int npow, hipStream_t st);
+// separable propagator tables of the fused loop: px[m1] (carries 1 / (m1 m2)), py[m2], n-th power
+hipError_t k_build_propagator_1d(float2* px, float2* py, const KP& p, int npow, hipStream_t st);
 hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, hipStream_t st);
 hipError_t k_lens(float2* psi, const KP& p, float defocus_k, hipStream_t st);
 hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre_scale, float alpha, hipStream_t st);

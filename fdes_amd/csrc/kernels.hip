@@ -44,6 +44,15 @@ __global__ void kk_fill(float2* __restrict__ f, size_t n, float re, float im)
 {
     GS_LOOP(i, n) f[i] = make_float2(re, im);
 }
+// pseudo-random fill in [-1, 1) for the micro-benchmarks (zero-filled grids run at a higher clock than real data)
+__global__ void kk_fill_noise(float* __restrict__ f, size_t n, unsigned seed)
+{
+    GS_LOOP(i, n) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        f[i] = (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f;
+    }
+}
 __global__ void kk_scale(float2* __restrict__ f, size_t n, float a)
 {
     GS_LOOP(i, n) { float2 v = f[i]; v.x *= a; v.y *= a; f[i] = v; }
@@ -225,31 +234,26 @@ __global__ void kk_propagator(float2* __restrict__ P, KP p, int transposed)
     }
 }
 
-// n consecutive slices without atoms are n Fresnel steps: psi <- F^-1[P^n F[psi]].  P^n = alpha exp(i n phi) inside the
-// band (one FFT pair, so one alpha): phi is the FLOAT phase of kk_propagator (what the reference multiplies n times),
-// n phi and its sine / cosine are taken in double so that the run does not add rounding of its own.
-__global__ void kk_propagator_pow(float2* __restrict__ P, KP p, int transposed, int npow)
+// Separable form of the same propagator for the fused slice loop: P(i1, i2) = px[i1] * py[i2] inside the band limit,
+// px[i1] = alpha exp(i n phi1(i1)), py[i2] = exp(i n phi2(i2)), phi = -pi t^2 lambda / d3 with t as in kk_propagator; the
+// phases, their n-fold multiples (n consecutive slices without atoms are n Fresnel steps: one transform pair, so one
+// alpha) and the sines / cosines are taken in double from the same float inputs, so the product of the two factors is
+// within float32 rounding of the exact value (the reference's float32 phase is a few 1e-8 rad further away).
+__global__ void kk_propagator_1d(float2* __restrict__ px, float2* __restrict__ py, KP p, int npow)
 {
-    const size_t n = (size_t)p.m1 * p.m2;
-    const float mindim = (float)(p.m1 < p.m2 ? p.m1 : p.m2);
-    const float alpha = 1.f / ((float)(p.m1 * p.m2));
+    const size_t n = (size_t)p.m1 + (size_t)p.m2;
+    const double alpha = 1.0 / ((double)p.m1 * (double)p.m2);
     GS_LOOP(i, n)
     {
-        const int j1 = transposed ? (int)(i / (size_t)p.m2) : (int)(i % (size_t)p.m1);
-        const int j2 = transposed ? (int)(i % (size_t)p.m2) : (int)(i / (size_t)p.m1);
-        const int i1 = iw(j1, p.m1), i2 = iw(j2, p.m2);
-        float d3 = p.d3;
-        const float t1 = ((float)(i1) / ((float)p.m1)) * (d3 / p.d1);
-        const float t2 = ((float)(i2) / ((float)p.m2)) * (d3 / p.d2);
-        d3 = p.lambda / d3;
-        d3 = -PI_F * (t1 * t1 + t2 * t2) * d3;
+        const bool isx = i < (size_t)p.m1;
+        const int m = isx ? p.m1 : p.m2;
+        const int j = iw((int)(isx ? i : i - (size_t)p.m1), m);
+        const double t = ((double)j / (double)m) * ((double)p.d3 / (double)(isx ? p.d1 : p.d2));
+        const double ph = -3.14159265358979323846 * t * t * ((double)p.lambda / (double)p.d3) * (double)npow;
         double sn, cs;
-        sincos((double)d3 * (double)npow, &sn, &cs);
-        float2 v = make_float2((float)cs, (float)sn);
-        if (outside_band(i1, i2, mindim)) v = make_float2(0.f, 0.f);
-        v.x *= alpha;
-        v.y *= alpha;
-        P[i] = v;
+        sincos(ph, &sn, &cs);
+        const double a = isx ? alpha : 1.0;
+        (isx ? px[i] : py[i - (size_t)p.m1]) = make_float2((float)(a * cs), (float)(a * sn));
     }
 }
 
@@ -490,6 +494,7 @@ __global__ void kk_scale_by(float2* __restrict__ f, size_t n, float target, cons
     } while (0)
 
 hipError_t k_fill(float2* f, size_t n, float re, float im, hipStream_t st) { LAUNCH(kk_fill, n, st, f, n, re, im); }
+hipError_t k_fill_noise(float* f, size_t n, unsigned seed, hipStream_t st) { LAUNCH(kk_fill_noise, n, st, f, n, seed); }
 hipError_t k_scale(float2* f, size_t n, float a, hipStream_t st) { LAUNCH(kk_scale, n, st, f, n, a); }
 hipError_t k_axpy(float2* y, const float2* x, size_t n, float a, hipStream_t st) { LAUNCH(kk_axpy, n, st, y, x, n, a); }
 hipError_t k_filter_accum(float2* Vh, float2* Dh, const KP& p, const Kirk& kz, int first, hipStream_t st)
@@ -506,7 +511,7 @@ hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st)
 }
 hipError_t k_mul(float2* dst, const float2* f0, const float2* f1, size_t n, hipStream_t st) { LAUNCH(kk_mul, n, st, dst, f0, f1, n); }
 hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_t st) { LAUNCH(kk_propagator, (size_t)p.m1 * p.m2, st, P, p, transposed); }
-hipError_t k_build_propagator_pow(float2* P, const KP& p, int transposed, int npow, hipStream_t st) { LAUNCH(kk_propagator_pow, (size_t)p.m1 * p.m2, st, P, p, transposed, npow); }
+hipError_t k_build_propagator_1d(float2* px, float2* py, const KP& p, int npow, hipStream_t st) { LAUNCH(kk_propagator_1d, (size_t)p.m1 + p.m2, st, px, py, p, npow); }
 hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, hipStream_t st) { LAUNCH(kk_gtab, (size_t)p.m1 * p.m2, st, G, p, kz, transposed); }
 hipError_t k_lens(float2* psi, const KP& p, float dk, hipStream_t st) { LAUNCH(kk_lens, (size_t)p.m1 * p.m2, st, psi, p, dk); }
 hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre, float alpha, hipStream_t st)
