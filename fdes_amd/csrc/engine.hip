@@ -49,6 +49,7 @@ struct fdes_ctx {
     int lanes_active = 0; // > 0: run_config only deals to the first n lanes (bench: time a kernel without a co-running lane)
     int lanes = 0;        // configurations in flight at once (own stream + buffers each) in the fused slice loop; 0: by grid size
     int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
+    int pitch_pad = -1;   // elements added to every row of the fused loop's grids; -1 auto: 64 from 4096-point rows on
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
     // plans are expensive to create: one per grid size AND requested back-end (option "fft" may change between plans)
     std::map<std::tuple<int, int, int>, Fft2D*> fft_cache;
@@ -106,6 +107,12 @@ struct fdes_plan {
     float2 *A = nullptr, *B = nullptr, *C = nullptr, *C2 = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
     float* GT = nullptr;
     bool tables_shared = false; // PT / GT belong to the parent plan (lanes)
+    // Row pitches of the fused loop's grids (elements): "N" grids [y][kx] have m2 rows of pitchN >= m1, "T" grids [kx][y|ky]
+    // have m1 rows of pitchT >= m2.  A transposed store writes one short segment into each of several thousand rows: with
+    // rows a power of two apart these segments pile up on a few memory channels once the working set leaves the
+    // Infinity Cache (4096^2, two streams: 95.6 us for a transposing copy against 60-67 us with 64 elements of padding).
+    int pitchN = 0, pitchT = 0;
+    size_t gsz = 0;             // elements of one fused grid (either layout)
     // P^n tables (separable: m1 + m2 complex numbers) for runs of n empty slices (skip_empty): built on first use on this
     // plan's stream, least recently used of 16 replaced
     struct PowTab { int n; float2* tab; uint64_t used; };
@@ -314,8 +321,10 @@ int forward_propagation(fdes_plan* pl, int comp = -1)
 //   P4  C[kx][y]       -FFT_y, band limit / m12, IFFT_y-> E[y][kx]
 //   P5  E, PSIH[y][kx] -IFFT_x both, t * psi, FFT_x->    F[kx][y]
 //   P6  F[kx][y]       -FFT_y, * P, IFFT_y->             PSIH[y][kx]
-PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; a.wg = pl->wg; return a; }
-PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; a.wg = pl->wg; return a; }
+// pass over the rows of an "N" grid ([y][kx], row length m1) with a transposed store into a "T" grid, and the reverse;
+// callers whose input or output is a dense natural grid (PSI, T, user buffers) override the pitch with 0
+PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; a.wg = pl->wg; a.pitch_in = pl->pitchN; a.pitch_out = pl->pitchT; return a; }
+PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; a.wg = pl->wg; a.pitch_in = pl->pitchT; a.pitch_out = pl->pitchN; return a; }
 
 // Potential of the slice PAIR (s0, s0 + 1), s0 even: W = V_s0 + i V_(s0+1) (the deposits are real and the filter
 // G is real and even, so one complex transform carries two slices).  P1' builds the x-spectra of the deposit rows
@@ -327,14 +336,14 @@ int fused_potential_pair(fdes_plan* pl, int s0)
     {   // one launch, grid.y = species
         PassArgs a = pass_x(pl);
         a.out = pl->A;
-        a.nspecies = pl->nZ; a.species_stride = pl->m12;
+        a.nspecies = pl->nZ; a.species_stride = pl->gsz;
         a.recs = pl->bins.recs_sorted; a.rowstart = pl->bins.rowstart;
         a.q0 = s0 * pl->nZ;
         a.q1 = (s0 + 1 < pl->p.m3) ? (s0 + 1) * pl->nZ : -1;
         HIPCHK(c, lds_pass(m1, XF_FWD, MID_ATOMS, XF_NONE, true, a, c->stream));
     }
     PassArgs b = pass_y(pl);
-    b.in0 = pl->A; b.gtab = pl->GT; b.out = pl->B; b.nspecies = pl->nZ; b.species_stride = pl->m12;
+    b.in0 = pl->A; b.gtab = pl->GT; b.out = pl->B; b.nspecies = pl->nZ; b.species_stride = pl->gsz;
     HIPCHK(c, lds_pass(m2, XF_FWD, pl->nZ == 1 ? MID_GTAB : MID_GTABN, XF_INV, true, b, c->stream));
     return FDES_OK;
 }
@@ -451,6 +460,7 @@ int fused_enter(fdes_plan* pl)
 {
     PassArgs a = pass_x(pl);
     a.in0 = pl->PSI; a.out = pl->PSIH;
+    a.pitch_in = 0; a.pitch_out = pl->pitchN; // dense real-space wave -> padded mixed representation, natural store
     HIPCHK(pl->ctx, lds_pass(pl->p.m1, XF_FWD, MID_NONE, XF_NONE, false, a, pl->ctx->stream));
     return FDES_OK;
 }
@@ -463,6 +473,7 @@ int fused_leave(fdes_plan* pl, bool propagated)
         a.band = md * md;
         a.skip_dead_loads = 1;
     }
+    a.pitch_out = 0; // dense
     a.scale = 1.f / (float)pl->p.m1; // PSIH = FFT_x(psi), unnormalised transforms (m1 is a power of two: exact)
     HIPCHK(pl->ctx, lds_pass(pl->p.m1, XF_INV, MID_SCALE, XF_NONE, false, a, pl->ctx->stream));
     return FDES_OK;
@@ -762,6 +773,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
     if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "pitch_pad")) { if (value < -1 || value > 1024 || (value > 0 && value % 2)) return FDES_EINVAL; c->pitch_pad = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_alt")) { c->bench_alt = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_tall")) { if (value < 1 || value > 4) return FDES_EINVAL; c->bench_tall = (int)value; return FDES_OK; }
@@ -907,7 +919,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     pl->fused = pl->fft->backend == 2;
     if (!pl->fused) { // filter table of the generic path (natural layout)
         PLCHK(dmalloc(c, &pl->GT, pl->m12 * (size_t)pl->nZ));
-        for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 0, c->stream));
+        for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 0, 0, c->stream));
     }
     if (pl->fused) {
         const int m1 = pl->p.m1, m2 = pl->p.m2;
@@ -925,25 +937,33 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // lanes share the read-only tables PT / GT: 4 grids per lane + the tables instead of 7.5 per lane, so that two
         // lanes at 2048^2 (304 MiB) mostly stay inside the 256 MiB Infinity Cache.  Dead (band-limited) rows of C / F
         // may hold stale data of the other tenant: P4 / P6 never read them.
-        PLCHK(dmalloc(c, &pl->C, pl->m12));
+        {
+            const int pad = c->pitch_pad >= 0 ? c->pitch_pad : ((m1 >= 4096 || m2 >= 4096) ? 64 : 0);
+            pl->pitchN = m1 + pad;
+            pl->pitchT = m2 + pad;
+            const size_t gn = (size_t)pl->pitchN * (size_t)m2, gt = (size_t)pl->pitchT * (size_t)m1;
+            pl->gsz = gn > gt ? gn : gt;
+        }
+        PLCHK(dmalloc(c, &pl->C, pl->gsz));
         pl->F = pl->C;
         if (pl->nZ == 1) pl->A = pl->C;
-        else PLCHK(dmalloc(c, &pl->A, pl->m12 * (size_t)pl->nZ));
-        PLCHK(dmalloc(c, &pl->C2, pl->m12)); // x-spectrum of the transmission function of the pair's second slice
-        PLCHK(dmalloc(c, &pl->E, pl->m12));
+        else PLCHK(dmalloc(c, &pl->A, pl->gsz * (size_t)pl->nZ));
+        PLCHK(dmalloc(c, &pl->C2, pl->gsz)); // x-spectrum of the transmission function of the pair's second slice
+        PLCHK(dmalloc(c, &pl->E, pl->gsz));
         pl->B = pl->E; // the packed pair potential is consumed by P3 before P4 writes E
-        PLCHK(dmalloc(c, &pl->PSIH, pl->m12));
+        PLCHK(dmalloc(c, &pl->PSIH, pl->gsz));
         if (c->share_PT) { pl->PT = c->share_PT; pl->GT = c->share_GT; pl->tables_shared = true; }
         else {
             PLCHK(dmalloc(c, &pl->PT, (size_t)pl->p.m1 + (size_t)pl->p.m2));
-            PLCHK(dmalloc(c, &pl->GT, pl->m12 * (size_t)pl->nZ));
+            PLCHK(dmalloc(c, &pl->GT, pl->gsz * (size_t)pl->nZ));
         }
         PLCHK(dmalloc(c, &pl->bins.rowstart, (size_t)pl->p.m3 * pl->nZ * (size_t)(pl->p.m2 + 1)));
         // dead (band-limited) rows / columns of these grids are never written again: they must read as zero
-        for (float2* q : {pl->C, pl->C2, pl->E, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->m12, c->stream));
+        for (float2* q : {pl->C, pl->C2, pl->E, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->gsz, c->stream));
         if (!pl->tables_shared) {
             PLHIP(k_build_propagator_1d(pl->PT, pl->PT + pl->p.m1, pl->kp, 1, c->stream));
-            for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->m12, pl->kp, pl->kz[z], 1, c->stream));
+            PLHIP(hipMemsetAsync(pl->GT, 0, sizeof(float) * pl->gsz * (size_t)pl->nZ, c->stream));
+            for (int z = 0; z < pl->nZ; z++) PLHIP(k_build_gtab(pl->GT + (size_t)z * pl->gsz, pl->kp, pl->kz[z], 1, pl->pitchT, c->stream));
         }
     }
     // tilt offset (src/crystalMaker.cu:282-283)
@@ -962,7 +982,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             PLCHK(create_ctx(&lc, c->device, nlanes >= 3 ? (l <= 2 ? l : 0) : 0));
             lc->is_lane_ctx = true;
             // frozen here: fft, lanes, pass_threads (they shape the lane plan); the others are read through owner_ctx()
-            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip;
+            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad;
             lc->share_PT = pl->PT; lc->share_GT = pl->GT; // read-only tables of the parent plan (built and synchronised above)
             pl->lane_ctx.push_back(lc);
             fdes_plan* lp = nullptr;
@@ -1268,7 +1288,7 @@ int fdes_plan_tap_potential(fdes_plan* pl, int k, int j, int s, float* V)
     if (pl->fused) {
         RC(fused_potential_pair(pl, s & ~1));
         PassArgs a = pass_x(pl);
-        a.in0 = pl->B; a.out = pl->T;
+        a.in0 = pl->B; a.out = pl->T; a.pitch_out = 0;
         HIPCHK(c, lds_pass(pl->p.m1, XF_INV, MID_NONE, XF_NONE, false, a, c->stream));
         HIPCHK(c, k_pick_potential(pl->VH, pl->T, pl->m12, s & 1, pl->p.imPot, c->stream));
     } else {
@@ -1318,7 +1338,7 @@ int fdes_plan_propagate_dev(fdes_plan* pl, void* psi_dev, const void* t_dev, int
             float2* psi = (float2*)psi_dev + (size_t)b * pl->m12;
             const float2* t = (const float2*)t_dev + (t_per_wave ? (size_t)b * pl->m12 : 0);
             PassArgs a5 = pass_x(pl);
-            a5.in0 = t; a5.in1 = psi; a5.out = pl->F;
+            a5.in0 = t; a5.in1 = psi; a5.out = pl->F; a5.pitch_in = 0; // caller's dense grids
             a5.band = band; a5.skip_dead_stores = bs;
             HIPCHK(c, lds_pass(m1, XF_NONE, MID_MULPSI, XF_FWD, true, a5, c->stream));
             PassArgs a6 = pass_y(pl);
@@ -1326,7 +1346,7 @@ int fdes_plan_propagate_dev(fdes_plan* pl, void* psi_dev, const void* t_dev, int
             a6.band = band; a6.live_rows_only = bs;
             HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
             PassArgs a7 = pass_x(pl);
-            a7.in0 = pl->E; a7.out = psi; a7.scale = 1.f;
+            a7.in0 = pl->E; a7.out = psi; a7.scale = 1.f; a7.pitch_out = 0;
             if (bs) { a7.band = band; a7.skip_dead_loads = 1; } // dead kx columns of E are never written: they count as zero
             HIPCHK(c, lds_pass(m1, XF_INV, MID_SCALE, XF_NONE, false, a7, c->stream));
         }

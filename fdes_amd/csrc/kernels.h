@@ -35,7 +35,7 @@ hipError_t k_mul(float2* dst, const float2* f0, const float2* f1, size_t n, hipS
 hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_t st);
 // separable propagator tables of the fused loop: px[m1] (carries 1 / (m1 m2)), py[m2], n-th power
 hipError_t k_build_propagator_1d(float2* px, float2* py, const KP& p, int npow, hipStream_t st);
-hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, hipStream_t st);
+hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, int pitch, hipStream_t st);
 hipError_t k_lens(float2* psi, const KP& p, float defocus_k, hipStream_t st);
 hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre_scale, float alpha, hipStream_t st);
 hipError_t k_tilt_beam(float2* psi, const KP& p, float tb0, float tb1, int flag, hipStream_t st);

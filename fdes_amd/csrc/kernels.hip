@@ -128,7 +128,7 @@ __global__ void kk_transmit_comp(float2* __restrict__ t, const float2* __restric
 
 // Same filter as kk_filter_accum, tabulated once per plan and species (it does not depend on the
 // slice): g_Z(q) = f_e(q^2) * 4.78776452e-9 sigma / (d1 d2 m12) * x/sin x * y/sin y.
-__global__ void kk_gtab(float* __restrict__ G, KP p, Kirk kz, int transposed)
+__global__ void kk_gtab(float* __restrict__ G, KP p, Kirk kz, int transposed, int pitch)
 {
     const size_t n = (size_t)p.m1 * p.m2;
     const float d1 = 1e10f * p.d1, d2 = 1e10f * p.d2;
@@ -150,7 +150,7 @@ __global__ void kk_gtab(float* __restrict__ G, KP p, Kirk kz, int transposed)
         x = (x + FLT_EPSILON) / (sinf(x) + FLT_EPSILON);
         y *= ((float)i2) / ((float)p.m2);
         x *= (y + FLT_EPSILON) / (sinf(y) + FLT_EPSILON);
-        G[i] = g * x;
+        G[(transposed && pitch > 0) ? (size_t)j1 * (size_t)pitch + (size_t)j2 : i] = g * x; // pitch: padded rows of the transposed table
     }
 }
 
@@ -512,7 +512,7 @@ hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st)
 hipError_t k_mul(float2* dst, const float2* f0, const float2* f1, size_t n, hipStream_t st) { LAUNCH(kk_mul, n, st, dst, f0, f1, n); }
 hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_t st) { LAUNCH(kk_propagator, (size_t)p.m1 * p.m2, st, P, p, transposed); }
 hipError_t k_build_propagator_1d(float2* px, float2* py, const KP& p, int npow, hipStream_t st) { LAUNCH(kk_propagator_1d, (size_t)p.m1 + p.m2, st, px, py, p, npow); }
-hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, hipStream_t st) { LAUNCH(kk_gtab, (size_t)p.m1 * p.m2, st, G, p, kz, transposed); }
+hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, int pitch, hipStream_t st) { LAUNCH(kk_gtab, (size_t)p.m1 * p.m2, st, G, p, kz, transposed, pitch); }
 hipError_t k_lens(float2* psi, const KP& p, float dk, hipStream_t st) { LAUNCH(kk_lens, (size_t)p.m1 * p.m2, st, psi, p, dk); }
 hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre, float alpha, hipStream_t st)
 {

@@ -7,10 +7,11 @@ import numpy as np
 import fdes_amd
 from tests import specimens as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+opts = dict(kv.split("=") for kv in sys.argv[2:])   # e.g. pitch_pad=0 lanes=1
 hp, at = S.case_c5()
 fdes_amd.consistent(hp)
-print("atoms", at.n, "grid", hp.c.m1, "slices", hp.c.m3, flush=True)
-eng = fdes_amd.Engine(0, skip_empty=0)
+print("atoms", at.n, "grid", hp.c.m1, "slices", hp.c.m3, "options", opts, flush=True)
+eng = fdes_amd.Engine(0, skip_empty=0, **{k: int(v) for k, v in opts.items()})
 t0 = time.perf_counter()
 pl = eng.plan(hp, at)
 pl.begin_measurement(0)
