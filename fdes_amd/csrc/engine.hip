@@ -49,6 +49,7 @@ struct fdes_ctx {
     int lanes_active = 0; // > 0: run_config only deals to the first n lanes (bench: time a kernel without a co-running lane)
     int lanes = 0;        // configurations in flight at once (own stream + buffers each) in the fused slice loop; 0: by grid size
     int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
+    int walk = 1;         // row groups per pass workgroup (2: a pass takes half of the workgroup slots, two lanes' passes share every CU)
     int pitch_pad = -1;   // elements added to every row of the fused loop's grids; -1 auto: 64 from 4096-point rows on
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
     // plans are expensive to create: one per grid size AND requested back-end (option "fft" may change between plans)
@@ -323,8 +324,8 @@ int forward_propagation(fdes_plan* pl, int comp = -1)
 //   P6  F[kx][y]       -FFT_y, * P, IFFT_y->             PSIH[y][kx]
 // pass over the rows of an "N" grid ([y][kx], row length m1) with a transposed store into a "T" grid, and the reverse;
 // callers whose input or output is a dense natural grid (PSI, T, user buffers) override the pitch with 0
-PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; a.wg = pl->wg; a.pitch_in = pl->pitchN; a.pitch_out = pl->pitchT; return a; }
-PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; a.wg = pl->wg; a.pitch_in = pl->pitchT; a.pitch_out = pl->pitchN; return a; }
+PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; a.wg = pl->wg; a.pitch_in = pl->pitchN; a.pitch_out = pl->pitchT; a.walk = owner_ctx(pl)->walk; return a; }
+PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; a.wg = pl->wg; a.pitch_in = pl->pitchT; a.pitch_out = pl->pitchN; a.walk = owner_ctx(pl)->walk; return a; }
 
 // Potential of the slice PAIR (s0, s0 + 1), s0 even: W = V_s0 + i V_(s0+1) (the deposits are real and the filter
 // G is real and even, so one complex transform carries two slices).  P1' builds the x-spectra of the deposit rows
@@ -523,6 +524,7 @@ int slice_loop(fdes_plan* pl, int nslices)
         pattern.reserve((size_t)pl->p.m3 + 8);
         for (int b = 0; b < 4; b++) pattern.push_back((uint8_t)((unsigned)nslices >> (8 * b)));
         pattern.push_back((uint8_t)oc->band_skip);
+        pattern.push_back((uint8_t)oc->walk);
         pattern.push_back(pl->seg_h.empty() ? 0 : 1);
         if (!pl->seg_h.empty())
             for (int q = 0; q < pl->p.m3; q++) pattern.push_back(pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ] ? 2 : 3);
@@ -773,6 +775,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
     if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "walk")) { if (value < 1 || value > 8) return FDES_EINVAL; c->walk = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "pitch_pad")) { if (value < -1 || value > 1024 || (value > 0 && value % 2)) return FDES_EINVAL; c->pitch_pad = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_alt")) { c->bench_alt = (int)value; return FDES_OK; }
@@ -1423,6 +1426,7 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
         PassArgs A;
         A.in0 = a; A.in1 = b; A.out = o; A.out2 = o2; A.zsrc = a; A.gtab = g; A.prow = pt; A.pcol = pt + n * c->bench_tall; A.tw0 = f.tw0x; A.tw1 = f.tw1x; A.nrows = n * c->bench_tall;
         A.nspecies = 1; A.species_stride = m12; A.scale = 1.f; A.mindim = n;
+        A.walk = c->walk;
         if (c->bench_pitch) { A.pitch_in = n + c->bench_pitch; A.pitch_out = (store_t ? n * c->bench_tall : n) + c->bench_pitch; }
         A.wg = c->pass_threads == 256 ? 256 : ((c->pass_threads == 513 || c->pass_threads == 1) && n <= 2048 ? 1 : 512);
         if (c->bench_band) { // micro-benchmark of the band-limit bookkeeping: bit 0 live rows only, bit 1 dead loads, bit 2 dead stores

@@ -48,6 +48,9 @@ struct PassArgs {
     // pitch_out: distance between output rows (natural store: default n; transposed store: default nrows).  A pitch
     // that is not a power of two spreads the 2^k-strided segments of a transposed store over the memory channels.
     int pitch_in = 0, pitch_out = 0;
+    // walk > 1: the pass is launched in `walk` parts of about 1 / walk of the row groups each (half of the chip's
+    // workgroup slots at walk = 2); nvirt, vb0 (set by lds_pass) = number of row groups, first group of this part
+    int walk = 1, nvirt = 0, vb0 = 0;
     int nspecies = 1;
     size_t species_stride = 0;   // elements between species grids (in0 and gtab)
     float scale = 1.f;

@@ -278,8 +278,35 @@ struct Tw {
     const float2* g0;
     const float2* g1;
     float2 r0[16], r1[16];
+    float2 b0[6], b1[6]; // TWM_POW: w^1, w^2, w^3, w^4, w^8, w^12 of each stage
 };
-template <int N, int WG, bool INV, bool WAR0, bool TWR>
+// Twiddle modes of a pass: fetched from the tables at the point of use (no registers, 30 loads per transform in the
+// middle of the arithmetic), all 30 in registers for the whole pass (60 VGPRs: only where the kernel stays under 256
+// without spilling), or six powers of each stage in registers (w^1, w^2, w^3, w^4, w^8, w^12: 24 VGPRs) and the other
+// nine as ONE complex product each per transform (+36 packed instructions, no load).  One product, not a chain: the
+// twiddle errors are the same in every transform of every slice, so they add up coherently over a slice loop and
+// dominate the float32 error of an exit wave (2048^2 x 256 slices against the float64 oracle: 2.0e-5 with table
+// twiddles, 3.8e-5 with chains of up to three products from w^1, w^2, w^4, w^8).  The products are rebuilt in every
+// transform: an empty asm makes the base values opaque, otherwise the compiler computes all powers once and keeps
+// them alive across the pass (which is the 60-register mode again).
+enum { TWM_FETCH = 0, TWM_REGS = 1, TWM_POW = 2 };
+__device__ __forceinline__ void tw_opaque(cf& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void tw_powers(const cf (&b)[6], cf (&w)[16])
+{
+    cf lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]}; // w^1..w^3, w^4, w^8, w^12
+#pragma unroll
+    for (int i = 0; i < 3; i++) { tw_opaque(lo[i]); tw_opaque(hi[i]); }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        w[1 + i] = lo[i];
+        w[4 * (i + 1)] = hi[i];
+    }
+#pragma unroll
+    for (int h = 0; h < 3; h++)
+#pragma unroll
+        for (int l = 0; l < 3; l++) w[4 * (h + 1) + l + 1] = cmul(hi[h], lo[l]);
+}
+template <int N, int WG, bool INV, bool WAR0, int TWR>
 __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* __restrict__ lds, const int r, const int t, const Tw& tw,
                                         GroupSync& gs)
 {
@@ -290,11 +317,15 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
     // ---- stage 0
 #pragma unroll
     for (int h = 0; h < WGeo<WG>::NRV; h++) r16<INV>(a[h]);
+    {
+        float2 wp[16];
+        if constexpr (TWR == TWM_POW) tw_powers(tw.b0, wp);
 #pragma unroll
-    for (int k = 1; k < 16; k++) {
-        const float2 w = TWR ? tw.r0[k] : tw.g0[k * T + t];
+        for (int k = 1; k < 16; k++) {
+            const float2 w = TWR == TWM_POW ? wp[k] : (TWR == TWM_REGS ? tw.r0[k] : tw.g0[k * T + t]);
 #pragma unroll
-        for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul<INV>(a[h][k], w);
+            for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul<INV>(a[h][k], w);
+        }
     }
     if (WAR0) group_sync<NW>(gs);
 #pragma unroll
@@ -315,9 +346,11 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
     for (int h = 0; h < WGeo<WG>::NRV; h++) r16<INV>(a[h]);
     if constexpr (G_::R3 > 1) {
         const int q = t & 15, p = t >> 4;
+        float2 wp[16];
+        if constexpr (TWR == TWM_POW) tw_powers(tw.b1, wp);
 #pragma unroll
         for (int k = 1; k < 16; k++) {
-            const float2 w = TWR ? tw.r1[k] : tw.g1[k * (T / 16) + p];
+            const float2 w = TWR == TWM_POW ? wp[k] : (TWR == TWM_REGS ? tw.r1[k] : tw.g1[k * (T / 16) + p]);
 #pragma unroll
             for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul<INV>(a[h][k], w);
         }
@@ -355,7 +388,7 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
     }
 }
 
-template <int N, int WG, int XF, bool WAR0, bool TWR>
+template <int N, int WG, int XF, bool WAR0, int TWR>
 __device__ __forceinline__ void xform(float2 (&a)[WGeo<WG>::NRV][16], float2* lds, int r, int t, const Tw& tw, GroupSync& gs)
 {
     if constexpr (XF == XF_FWD) row_fft<N, WG, false, WAR0, TWR>(a, lds, r, t, tw, gs);
@@ -374,6 +407,9 @@ __device__ __forceinline__ void xform(float2 (&a)[WGeo<WG>::NRV][16], float2* ld
 constexpr int pass_waves(int mid) { return (mid == MID_MULPSI || mid == MID_GTABN) ? 2 : FDES_WAVES; }
 #ifndef FDES_PAIR_TWR
 #define FDES_PAIR_TWR 0 // register twiddles in the two-slice transmission pass: 16 spilled registers at 2048; measured 38.3 / 30.7 us (one / two streams) against 37.2 / 28.7 us with fetched twiddles
+#endif
+#ifndef FDES_TWPOW
+#define FDES_TWPOW 2 // measured at 2048^2 (two lanes): 0 -> 13.1k, 1 -> 13.25k, 2 -> 14.4k slice-propagations/s
 #endif
 #ifndef FDES_NO_TWR
 #define FDES_NO_TWR 0 // A/B switch: 1 = every pass fetches its stage twiddles at the point of use
@@ -440,7 +476,9 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
     extern __shared__ float2 lds[];
     STAMP(0, false);
     STAMP(15, false); // wall clock (100 MHz) of the same instant
-    constexpr bool TWR = !FDES_NO_TWR && (pass_waves(MID) == 2) && (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && (MID != MID_PTAB || FDES_PTAB_TWR) && MID != MID_GTABN && (MID != MID_EXPIV_PAIR || (FDES_PAIR_TWR && N <= 2048)));
+    constexpr bool TWREG = !FDES_NO_TWR && (pass_waves(MID) == 2) && (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && (MID != MID_PTAB || FDES_PTAB_TWR) && MID != MID_GTABN && (MID != MID_EXPIV_PAIR || (FDES_PAIR_TWR && N <= 2048)));
+    // FDES_TWPOW: 0 = never, 1 = in the passes that cannot afford the 60 twiddle registers, 2 = in every two-rows-per-thread pass
+    constexpr int TWR = (FDES_TWPOW == 2 && WGeo<WG>::NRV == 2) ? TWM_POW : (TWREG ? TWM_REGS : ((FDES_TWPOW == 1 && WGeo<WG>::NRV == 2) ? TWM_POW : TWM_FETCH));
     Tw tw;
     tw.g0 = reinterpret_cast<const float2*>(A.tw0);
     tw.g1 = reinterpret_cast<const float2*>(A.tw1);
@@ -454,13 +492,19 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
         if (threadIdx.x < WGeo<WG>::THR / 64) cnts[threadIdx.x] = 0;
         __syncthreads();
     }
-    // (Measured and dropped: letting a workgroup walk several row groups so that a 256-thread kernel leaves one
-    // LDS slot per CU to another stream's kernel was slower than plain one-group workgroups on two streams.)
     const int tid = threadIdx.x;
     const int r = tid / T, t = tid % T;
-    // this thread's stage twiddles, loaded once (they serve every transform of the pass and both rows); issued first so
-    // their latency hides behind the row loads
-    if constexpr (TWR && (PRE != XF_NONE || POST != XF_NONE)) {
+    // A pass may be launched in parts (A.nvirt > 0: this launch covers the row groups vb0 .. vb0 + gridDim.x - 1 of
+    // nvirt; vb0 is a multiple of 8, so vb % 8 = blockIdx.x % 8): a part takes only a fraction of the chip's
+    // workgroup slots and leaves the rest of every CU to the kernel of another lane.  (An in-kernel loop over row
+    // groups was measured first: the loop alone costs the register allocator 40-200 spilled registers.)
+    const int nvirt = A.nvirt > 0 ? A.nvirt : (int)gridDim.x;
+    const int vb = (int)blockIdx.x + A.vb0;
+    if (vb >= nvirt) return;
+    // this thread's stage twiddles (they serve every transform of the pass and both rows); issued first so that their
+    // latency hides behind the row loads.  Per row group: hoisted out of the walk loop they would stay live across the
+    // whole body and cost more registers than the reload does time.
+    if constexpr (TWR == TWM_REGS && (PRE != XF_NONE || POST != XF_NONE)) {
 #pragma unroll
         for (int k = 1; k < 16; k++) tw.r0[k] = tw.g0[k * T + t];
         if constexpr (G_::R3 > 1) {
@@ -468,10 +512,19 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
             for (int k = 1; k < 16; k++) tw.r1[k] = tw.g1[k * (T / 16) + (t >> 4)];
         }
     }
+    if constexpr (TWR == TWM_POW && (PRE != XF_NONE || POST != XF_NONE)) {
+        constexpr int kBase[6] = {1, 2, 3, 4, 8, 12};
+#pragma unroll
+        for (int j = 0; j < 6; j++) tw.b0[j] = tw.g0[kBase[j] * T + t];
+        if constexpr (G_::R3 > 1) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) tw.b1[j] = tw.g1[kBase[j] * (T / 16) + (t >> 4)];
+        }
+    }
     // XCD-aware remap: blocks with equal blockIdx % 8 share an XCD; give them consecutive row groups
     int bg;
-    {   // bijective for any grid size: XCD x (= blockIdx % 8) owns a contiguous run of q or q + 1 groups
-        const int nwg = (int)gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+    {   // bijective for any grid size: XCD x (= vb % 8) owns a contiguous run of q or q + 1 groups
+        const int nwg = nvirt, q = nwg >> 3, rem = nwg & 7, xcd = vb & 7, k = vb >> 3;
         bg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
     }
     if (A.live_rows_only) {
@@ -829,19 +882,25 @@ template <int N, int WG, int PRE, int MID, int POST, bool ST> hipError_t launch(
         const int L = a.band_L;
         const int g_lo = L / G_::R + 1, g_hi = (a.nrows - L) / G_::R;
         if (g_hi > g_lo) groups = g_lo + (a.nrows / G_::R - g_hi); // else: everything is live
-        else { PassArgs b = a; b.live_rows_only = 0; hipLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, b); return hipGetLastError(); }
+        else { PassArgs b = a; b.live_rows_only = 0; b.walk = 1; hipLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, b); return hipGetLastError(); }
     }
-    if constexpr (MID == MID_ATOMS) { // grid.y = species (q0 / q1 are those of species 0, the grids are species_stride apart)
-        hipLaunchKernelGGL(kern, dim3(groups, a.nspecies > 0 ? a.nspecies : 1), dim3(WGeo<WG>::THR), lds_bytes, st, a);
+    PassArgs w = a;
+    const int ny = (MID == MID_ATOMS) ? (a.nspecies > 0 ? a.nspecies : 1) : 1; // grid.y = species (q0 / q1 are those of species 0, the grids are species_stride apart)
+    if (a.ev_start && a.ev_stop) { // timed launch: always whole
+        w.ev_start = w.ev_stop = nullptr;
+        hipExtLaunchKernelGGL(kern, dim3(groups, ny), dim3(WGeo<WG>::THR), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w);
         return hipGetLastError();
     }
-    if (a.ev_start && a.ev_stop) {
-        PassArgs b = a;
-        b.ev_start = b.ev_stop = nullptr;
-        hipExtLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, b);
-        return hipGetLastError();
+    int chunk = groups;
+    if (a.walk > 1) { // parts of about groups / walk workgroups (a multiple of 8, see the kernel), one launch each
+        chunk = ((groups + a.walk - 1) / a.walk + 7) & ~7;
+        if (chunk >= groups) chunk = groups;
     }
-    hipLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, a);
+    if (chunk < groups) w.nvirt = groups;
+    for (int v0 = 0; v0 < groups; v0 += chunk) {
+        w.vb0 = v0;
+        hipLaunchKernelGGL(kern, dim3(chunk < groups - v0 ? chunk : groups - v0, ny), dim3(WGeo<WG>::THR), lds_bytes, st, w);
+    }
     return hipGetLastError();
 }
 

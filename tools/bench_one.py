@@ -9,7 +9,8 @@ wg = int(sys.argv[6]) if len(sys.argv) > 6 else (256 if n <= 2048 else 512)
 eng = fdes_amd.Engine(0)
 eng.set_option("pass_threads", wg)
 eng.set_option("bench_band", band)
+eng.set_option("walk", int(os.environ.get("WALK", "1")))
 out = []
 for rep in range(3):
     out.append("/".join(f"{eng.bench_pass(n, pre, mid, post, 1, 200, ns):6.2f}" for ns in (1, 2)))
-print(os.path.basename(os.environ.get("FDES_LIB", "default")), f"n={n} ({pre},{mid},{post}) band={band} wg={wg}: x1/x2 us:", "  ".join(out), flush=True)
+print(os.path.basename(os.environ.get("FDES_LIB", "default")), f"n={n} ({pre},{mid},{post}) band={band} wg={wg} walk={os.environ.get('WALK', '1')}: x1/x2 us:", "  ".join(out), flush=True)

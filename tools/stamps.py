@@ -16,6 +16,7 @@ streams = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 eng = fdes_amd.Engine(0)
 eng.set_option("pass_threads", wg)
 eng.set_option("bench_band", band)
+eng.set_option("walk", int(os.environ.get("WALK", "1")))
 us = eng.bench_pass(n, pre, mid, post, 1, 20, streams)
 d = np.fromfile(f, np.uint64).reshape(-1, 16).astype(np.float64)
 os.unlink(f)
