@@ -409,7 +409,7 @@ constexpr int pass_waves(int mid) { return (mid == MID_MULPSI || mid == MID_GTAB
 #define FDES_PAIR_TWR 0 // register twiddles in the two-slice transmission pass: 16 spilled registers at 2048; measured 38.3 / 30.7 us (one / two streams) against 37.2 / 28.7 us with fetched twiddles
 #endif
 #ifndef FDES_TWPOW
-#define FDES_TWPOW 2 // measured at 2048^2 (two lanes): 0 -> 13.1k, 1 -> 13.25k, 2 -> 14.4k slice-propagations/s
+#define FDES_TWPOW 3 // 0 never, 1 passes without room for 60 twiddle registers, 2 every two-rows-per-thread pass, 3 every pass; measured at 2048^2 (two lanes): 0 -> 13.1k, 1 -> 13.25k, 2 -> 14.3k slice-propagations/s; 3 vs 2 at 1024^2 (C4, three lanes): 30.6k vs 28.0k
 #endif
 #ifndef FDES_NO_TWR
 #define FDES_NO_TWR 0 // A/B switch: 1 = every pass fetches its stage twiddles at the point of use
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
     STAMP(15, false); // wall clock (100 MHz) of the same instant
     constexpr bool TWREG = !FDES_NO_TWR && (pass_waves(MID) == 2) && (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && (MID != MID_PTAB || FDES_PTAB_TWR) && MID != MID_GTABN && (MID != MID_EXPIV_PAIR || (FDES_PAIR_TWR && N <= 2048)));
     // FDES_TWPOW: 0 = never, 1 = in the passes that cannot afford the 60 twiddle registers, 2 = in every two-rows-per-thread pass
-    constexpr int TWR = (FDES_TWPOW == 2 && WGeo<WG>::NRV == 2) ? TWM_POW : (TWREG ? TWM_REGS : ((FDES_TWPOW == 1 && WGeo<WG>::NRV == 2) ? TWM_POW : TWM_FETCH));
+    constexpr int TWR = ((FDES_TWPOW == 2 && WGeo<WG>::NRV == 2) || FDES_TWPOW == 3) ? TWM_POW : (TWREG ? TWM_REGS : ((FDES_TWPOW == 1 && WGeo<WG>::NRV == 2) ? TWM_POW : TWM_FETCH));
     Tw tw;
     tw.g0 = reinterpret_cast<const float2*>(A.tw0);
     tw.g1 = reinterpret_cast<const float2*>(A.tw1);
