@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--pitch-pad", type=int, default=-1, help="engine option pitch_pad (-1: by grid size)")
     ap.add_argument("--graph", type=int, default=1, help="engine option graph: replay the slice loop as a hipGraph")
     ap.add_argument("--extra-skip-run", type=int, default=1, help="also time the engine default (empty-slice short cut)")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="rank 0, N = 1: also time BASELINE config 5 (4096^2 x 512 slices) and the propagation-unit micro-benchmark "
+                         "(SURVEY 8d) so that they are driver-timed figures; reported under `extras`, never as the headline")
     ap.add_argument("--skip-empty", type=int, default=0,
                     help="1: slices without atoms only get the Fresnel step (engine default); 0 (bench default): every "
                          "slice runs the full potential/transmission/propagation sequence like the reference")
@@ -166,9 +169,9 @@ def main():
             # one rocFFT 2-D C2C = 2 passes x (8 B read + 8 B write) per pixel ("FFT pass 16 B/px")
             kname, alg_bytes = f"rocFFT 2-D C2C {m}x{m} (row + column kernels)", 32.0 * px
         ach = alg_bytes / per_launch_s / 1e9
-        traffic = pmc_traffic(m) if fused else None
+        traffic, stale = pmc_traffic(m) if fused else (None, False)
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_stale": stale,
                 "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": int(fft_n),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "timed": "HIP start/stop events of the dispatch itself (hipExtLaunchKernelGGL) on every %d-th launch during one "
@@ -187,6 +190,22 @@ def main():
         rel = float(np.linalg.norm(img1 - img0) / max(np.linalg.norm(img0), 1e-30))
         extra = {"value": round(world * args.steps * m3 / dt2, 2), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
                  "image_rel_diff_vs_headline_run": rel, "finite": fin2}
+    lanes_used = plan.lanes()
+    plan.close()
+    eng.close()
+    extras = None
+    if rank == 0 and world == 1 and args.extras and m == 2048:
+        extras = run_extras(local)
+    if roof is not None and fused:
+        # the whole slice step on the engine's own byte count: P1'/2 + P2/2 + P3/2 + P4 + P5 + P6 =
+        # 4 + 10 + 9.33 + 10.67 + 16 + 10.67 B per pixel and slice with the dead band-limit rows / columns not counted
+        bpp = ENGINE_BYTES_PER_PX_SLICE
+        roof["whole_step"] = {"bytes_per_px_slice": bpp, "achieved": round(bpp * px * (value / world) / 1e9, 1), "unit": "GB/s",
+                              "frac": round(bpp * px * (value / world) / 8e12, 4),
+                              "note": "all six passes of a slice at the measured rate; SURVEY 8d's fixed models beside it: "
+                                      "full step (176 + 56 nZ) B/px and propagation unit 80 B/px",
+                              "survey_full_step_model_GBps": round((176 + 56 * 1) * px * (value / world) / 1e9, 1),
+                              "survey_propagation_unit_model_GBps": round(80 * px * (value / world) / 1e9, 1)}
     if rank == 0:
         out = {
             "metric": "slice-propagations/sec", "value": round(value, 2), "unit": "slice-propagations/s",
@@ -196,37 +215,113 @@ def main():
                                    f"1 frozen-phonon configuration per step per GPU (of 32), mode 0",
                        "wave": [m, m], "slices": m3, "atoms": atoms.n, "configs_per_step": world,
                        "parallelism": f"configs sharded over {world} GPU(s)"},
-            "lanes": plan.lanes(), "graph": args.graph, "skip_empty": args.skip_empty,
-            # bytes the fused loop moves per pixel and slice (P1'/2 + P2/2 + P3 + P4 + P5 + P6 =
-            # 4 + 10 + 13.3 + 10.7 + 16 + 16, dead band-limit rows/columns not counted) at the measured rate, and the same
-            # rate priced with SURVEY 8d's model of separate FFT passes ((176 + 56 nZ) B/px; may exceed the HBM peak)
-            "engine_bytes_per_px_slice": 66, "engine_GBps": round(66 * px * (value / world) / 1e9, 1),
-            "survey_full_step_model_GBps": round((176 + 56 * 1) * px * (value / world) / 1e9, 1),
-            "survey_propagation_unit_model_GBps": round(80 * px * (value / world) / 1e9, 1),
+            "lanes": lanes_used, "graph": args.graph, "skip_empty": args.skip_empty,
             "lane_slice_loop_ms_per_slice": round(loop_ms / max(loop_slices, 1), 5),
             "slice_loop": "fused LDS passes" if fused else "rocFFT + point-wise kernels",
             "roofline": roof, "cpu_baseline": cpu, "finite": finite,
             "with_empty_slice_shortcut": extra,
+            "extras": extras,
         }
         print(json.dumps(out), flush=True)
-    plan.close()
-    eng.close()
     if world > 1:
         dist.destroy_process_group()
 
 
+ENGINE_BYTES_PER_PX_SLICE = 60.67
+
+
+def _blob_hash(path):
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def pmc_traffic(m):
     """HBM bytes per launch of the probed kernel (P5) from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
-    gfx950 correction + WRITE_SIZE; profiles/r01_pmc_traffic.json).  PMC counters cannot be collected from inside this
-    process, so the number is the offline measurement of the same kernel; None for sizes that were not profiled."""
+    gfx950 correction + WRITE_SIZE; profiles/r02_pmc.json, tools/profile_round.sh).  PMC counters cannot be collected from
+    inside this process, so the number is the offline measurement of the same kernel: the file records the git blob hash
+    of the kernel source it was measured on, and a different hash here returns (None, True) - stale - instead of a
+    number that may belong to another build.  (None, False) for sizes that were not profiled."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        for k, v in d.items():
-            if k.startswith(f"k_pass<{m},") and k.endswith("2, 5, 1, true>") and v.get("band_skip", 0) == 1:
-                return v["hbm_bytes_per_launch_corrected"]
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        src = "fdes_amd/csrc/fft_lds.hip"
+        if d.get("source_hash", {}).get(src) != _blob_hash(os.path.join(ROOT, src)):
+            return None, True
+        for wl in d["workloads"].values():
+            for k, v in wl.items():
+                if k.startswith(f"k_pass<{m},") and k.endswith("2, 5, 1, true>") and "hbm_bytes_per_launch_corrected" in v:
+                    return v["hbm_bytes_per_launch_corrected"], False
     except Exception:
         pass
-    return None
+    return None, False
+
+
+def run_extras(device):
+    """Driver-timed figures beside the headline (C5 and the SURVEY 8d micro-benchmark as bench keys)."""
+    import numpy as np
+    import torch
+    import fdes_amd
+    from tests import specimens
+    out = {}
+    # BASELINE config 5 at full size: Au cuboctahedron k = 60 (738 221 atoms), 4096^2 wave, 512 slices, every slice the
+    # full sequence; 2 untimed + 4 timed frozen-phonon configurations of the 16
+    hp, at = specimens.case_c5()
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(device, skip_empty=0)
+    pl = eng.plan(hp, at)
+    pl.begin_measurement(0)
+    for j in range(2):
+        pl.run_config(0, 100 + j, 0.0)
+    pl.sync()
+    torch.cuda.synchronize()
+    n = 4
+    t0 = time.perf_counter()
+    for j in range(n):
+        pl.run_config(0, j, 1.0 / 16)
+    pl.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pl.end_measurement(0)
+    img = pl.get_images()
+    rate = n * pl.m3 / dt
+    px = 4096 * 4096
+    out["c5"] = {"workload": f"C5 Au cuboctahedron k=60 ({at.n} atoms), 4096x4096 wave, {pl.m3} slices, {n} configurations timed",
+                 "value": round(rate, 1), "unit": "slice-propagations/s", "ms_per_step": round(dt / n * 1e3, 2),
+                 "lanes": pl.lanes(), "finite": bool(np.isfinite(img).all()),
+                 "whole_step": {"bytes_per_px_slice": ENGINE_BYTES_PER_PX_SLICE,
+                                "achieved": round(ENGINE_BYTES_PER_PX_SLICE * px * rate / 1e9, 1), "unit": "GB/s",
+                                "frac": round(ENGINE_BYTES_PER_PX_SLICE * px * rate / 8e12, 4)}}
+    pl.close()
+    eng.close()
+    # SURVEY 8d micro-benchmark: psi <- F^-1[P F[t psi]] on device-resident random psi and unit-modulus t, one stream,
+    # 256 units; priced with the survey's fixed 80 B/px model
+    out["propagation_unit"] = {}
+    for m in (2048, 4096):
+        hp, at = specimens.case_c3(k=2, n=m // 2, dn=m // 4, m3=2, frPh=0)
+        fdes_amd.consistent(hp)
+        eng = fdes_amd.Engine(device, lanes=1)
+        pl = eng.plan(hp, at)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        psi = torch.randn(1, m, m, 2, device="cuda", generator=g)
+        ph = (torch.rand(1, m, m, device="cuda", generator=g) * 2 - 1) * 3.14159265
+        t = torch.stack([torch.cos(ph), torch.sin(ph)], -1).contiguous()
+        torch.cuda.synchronize()
+        for _ in range(8):
+            pl.propagate_dev(psi.data_ptr(), t.data_ptr(), 1, True)
+        pl.sync()
+        reps = 256
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pl.propagate_dev(psi.data_ptr(), t.data_ptr(), 1, True)
+        pl.sync()
+        dt = time.perf_counter() - t0
+        r = reps / dt
+        out["propagation_unit"][str(m)] = {"units_per_s": round(r, 1), "us_per_unit": round(dt / reps * 1e6, 2),
+                                           "survey_80B_model_GBps": round(80 * m * m * r / 1e9, 1),
+                                           "survey_80B_model_frac": round(80 * m * m * r / 8e12, 4)}
+        pl.close()
+        eng.close()
+    return out
 
 
 def cpu_baseline(hp, atoms, m):

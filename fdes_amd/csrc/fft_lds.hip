@@ -37,6 +37,9 @@ constexpr float C2 = 0.707106781186547524f; // cos(pi/4)
 // <2 x float> adds / fmas and emits v_pk_add_f32 / v_pk_fma_f32 with op_sel / neg modifiers, instead of re-discovering
 // pairs by SLP (which packed unrelated scalars and cost a v_mov per four arithmetic instructions).
 typedef float cf __attribute__((ext_vector_type(2)));
+// (Exchange reads: where two of a thread's reads are less than 2 KiB apart the compiler merges them into ds_read2_b64.
+// Keeping them apart with `volatile` was measured: P4 18.3 -> 21.1 us, the two-slice transmission pass 35 -> 60 us -
+// the ordering constraints of volatile cost far more than the narrower instruction.)
 #define float2 cf
 #define make_float2(x, y) (cf{(x), (y)})
 __device__ __forceinline__ cf cmul(cf a, cf b) { return __builtin_elementwise_fma(a.yx, cf{-b.y, b.y}, a * b.xx); }

@@ -9,6 +9,8 @@ from tests import specimens as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 opts = dict(kv.split("=") for kv in sys.argv[2:])   # e.g. pitch_pad=0 lanes=1
 hp, at = S.case_c5()
+if "slices" in opts:   # shortened run for counter collection: the first slices of the same specimen
+    hp.set(m3=int(opts.pop("slices")))
 fdes_amd.consistent(hp)
 print("atoms", at.n, "grid", hp.c.m1, "slices", hp.c.m3, "options", opts, flush=True)
 eng = fdes_amd.Engine(0, skip_empty=0, **{k: int(v) for k, v in opts.items()})
