@@ -214,6 +214,28 @@ template <int NRV, class F, class M> __device__ __forceinline__ void expiv_all(c
     }
 }
 
+// t = exp(-imPot v) (cos v, sin v) for v = a.x (potential2Transmission, src/multisliceSimulation.cu:41-52, with the
+// absorptive part V.y = imPot V.x of src/crystalMaker.cu:101).  Without absorption (imPot = 0, a uniform value) the
+// exponential is exactly 1 and is not evaluated.
+template <int NRV> __device__ __forceinline__ void pair_transmission(cf (&a)[NRV][16], const float impot)
+{
+    if (impot == 0.f) {
+        expiv_all(a, [&](cf w, auto wide) {
+            float sn, cs;
+            sincos_sel<decltype(wide)::value>(w.x, sn, cs);
+            return cf{cs, sn};
+        }, [](cf w) { return fabsf(w.x); });
+    } else {
+        expiv_all(a, [&](cf w, auto wide) {
+            const float v = w.x;
+            float sn, cs;
+            const float e = __expf(-(v * impot));
+            sincos_sel<decltype(wide)::value>(v, sn, cs);
+            return cf{e * cs, e * sn};
+        }, [](cf w) { return fabsf(w.x); });
+    }
+}
+
 __device__ __forceinline__ int iwc(int i, int m) { return (i > m / 2) ? i - m : i; } // iwCoordIp
 // outside the radial 2/3 band limit for every value of the other index (zeroHighFreq: 9 (i1^2 + i2^2) > mindim^2)
 __host__ __device__ __forceinline__ bool dead_index(int i, int band) { return 9 * i * i > band; }
@@ -719,13 +741,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
             for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
                 for (int l = 0; l < 16; l++) vim[h][l] = a[h][l].y;
-            expiv_all(a, [&](float2 w, auto wide) {
-                const float v0 = w.x;
-                float sn, cs;
-                const float e0 = __expf(-(v0 * A.scale));
-                sincos_sel<decltype(wide)::value>(v0, sn, cs);
-                return make_float2(e0 * cs, e0 * sn);
-            }, [](float2 w) { return fabsf(w.x); });
+            pair_transmission(a, A.scale);
         } else if constexpr (MID == MID_MASK) {
             // zeroHighFreq tests (float)(i1^2 + i2^2) * 9 / mindim^2 > 1 (src/multisliceSimulation.cu:241).  On the
             // power-of-two grids this kernel serves, mindim^2 < 2^24, so every float on the deciding side of the
@@ -843,13 +859,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
         for (int h = 0; h < WGeo<WG>::NRV; h++)
 #pragma unroll
             for (int l = 0; l < 16; l++) a[h][l].x = vim[h][l];
-        expiv_all(a, [&](float2 w, auto wide) {
-            const float v1 = w.x;
-            float sn, cs;
-            const float e1 = __expf(-(v1 * A.scale));
-            sincos_sel<decltype(wide)::value>(v1, sn, cs);
-            return make_float2(e1 * cs, e1 * sn);
-        }, [](float2 w) { return fabsf(w.x); });
+        pair_transmission(a, A.scale);
         __syncthreads(); // every wave is done with the transpose tile before the second transform writes the row buffers
         xform<N, WG, POST, true, TWR>(a, lds, r, t, tw, gs);
         store_rows(a, reinterpret_cast<float2*>(A.out2));
