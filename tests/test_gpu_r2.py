@@ -238,6 +238,25 @@ def test_options_set_after_plan_creation_reach_every_lane(oracle):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("m", [256, 2048])
+def test_layout_and_launch_options_do_not_change_a_bit(m):
+    """Row padding (`pitch_pad`) and split launches (`walk`) change where data lives and how a pass is launched, not what
+    is computed: the exit wave must be bit-identical to the dense, whole-launch run."""
+    hp, at = S.case_tiny(m=m, m3=5, nz=2, nat=200, tilt=True, seed=71)
+    fdes_amd.consistent(hp)
+    waves = {}
+    for key, opts in {"dense": dict(pitch_pad=0, walk=1), "padded": dict(pitch_pad=64, walk=1), "odd pad": dict(pitch_pad=136, walk=1),
+                      "split": dict(pitch_pad=64, walk=2), "quarters": dict(pitch_pad=0, walk=4)}.items():
+        eng = fdes_amd.Engine(0, skip_empty=0, **opts)
+        pl = eng.plan(hp, at)
+        waves[key] = pl.tap_wave(0, 0)
+        pl.close()
+        eng.close()
+    for key, w in waves.items():
+        assert np.array_equal(w.view(np.float32), waves["dense"].view(np.float32)), key
+    assert np.isfinite(waves["dense"]).all() and np.abs(waves["dense"] - 1).max() > 1e-3   # not the vacuum wave
+
+
 def test_fft_option_is_part_of_the_plan_cache_key():
     hp, at = S.case_tiny(m=256, m3=2, nz=1, nat=10)
     fdes_amd.consistent(hp)
