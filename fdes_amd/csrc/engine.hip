@@ -896,7 +896,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLCHK(dmalloc(c, &pl->I, pl->m12));
     PLCHK(dmalloc(c, &pl->EW, pl->m12));
     PLCHK(dmalloc(c, &pl->J, (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3));
-    PLCHK(dmalloc(c, &pl->scal, (size_t)4));
+    PLCHK(dmalloc(c, &pl->scal, (size_t)1056)); // k_normalize_to: the sum + 1024 block partials
     PLHIP(hipMemsetAsync(pl->D, 0, sizeof(float2) * pl->m12, c->stream));
     PLHIP(hipMemsetAsync(pl->I, 0, sizeof(float2) * pl->m12, c->stream));
     PLHIP(hipMemsetAsync(pl->EW, 0, sizeof(float2) * pl->m12, c->stream));

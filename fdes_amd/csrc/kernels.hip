@@ -470,16 +470,33 @@ __global__ void kk_crop(float* __restrict__ J, const float2* __restrict__ I, KP 
 }
 
 // ---- cublasScnrm2 + Csscal of the CBED probe (src/multisliceSimulation.cu:578-580) -------------
-__global__ void kk_sumsq(const float2* __restrict__ f, size_t n, float* __restrict__ acc)
+// Deterministic: fixed grid, every block leaves its partial sum (grid-stride order, shuffle tree, four wave sums added
+// in order) in part[blockIdx.x], one block then adds the partials in a fixed tree.  (Round 1 added the block sums with a
+// float atomicAdd, whose order - and with it the last bits of every CBED image - changed from run to run.)
+constexpr int kSumBlocks = 1024;
+__global__ void kk_sumsq(const float2* __restrict__ f, size_t n, float* __restrict__ part)
 {
     float s = 0.f;
     GS_LOOP(i, n) { const float2 v = f[i]; s += v.x * v.x + v.y * v.y; }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    __shared__ float part[4];
+    __shared__ float ws[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) part[w] = s;
+    if (lane == 0) ws[w] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) part[1 + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+__global__ void kk_sum_partials(float* __restrict__ part, int nblocks)
+{
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += part[1 + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[0] = sh[0];
 }
 __global__ void kk_scale_by(float2* __restrict__ f, size_t n, float target, const float* __restrict__ acc)
 {
@@ -540,9 +557,10 @@ hipError_t k_noise(float2* f, size_t n, float dose, uint32_t seed, int k, hipStr
 hipError_t k_crop(float* J, const float2* I, const KP& p, hipStream_t st) { LAUNCH(kk_crop, (size_t)p.n1 * p.n2, st, J, I, p); }
 hipError_t k_normalize_to(float2* f, size_t n, float target, float* scratch, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kk_sumsq, grid_for(n), dim3(256), 0, st, f, n, scratch);
+    hipError_t e;
+    hipLaunchKernelGGL(kk_sumsq, dim3(kSumBlocks), dim3(256), 0, st, f, n, scratch); // scratch: 1 + kSumBlocks floats
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(kk_sum_partials, dim3(1), dim3(256), 0, st, scratch, kSumBlocks);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(kk_scale_by, grid_for(n), dim3(256), 0, st, f, n, target, scratch);
     return hipGetLastError();
