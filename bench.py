@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--probe-stride", type=int, default=8)
     ap.add_argument("--lanes", type=int, default=0, help="configurations in flight per GPU (engine option lanes)")
     ap.add_argument("--pass-threads", type=int, default=0)
+    ap.add_argument("--split", type=int, default=-1, help="engine option split: potential chain on a stream of its own (-1: engine default)")
     ap.add_argument("--walk", type=int, default=1, help="engine option walk: row groups per pass workgroup")
     ap.add_argument("--pitch-pad", type=int, default=-1, help="engine option pitch_pad (-1: by grid size)")
     ap.add_argument("--graph", type=int, default=1, help="engine option graph: replay the slice loop as a hipGraph")
@@ -78,7 +79,7 @@ def main():
     def timed_run(skip_empty):
         """K timed steps on a fresh engine/plan; returns (seconds, plan, engine, loop_ms, loop_slices, fft_ms, fft_n, finite)."""
         eng = fdes_amd.Engine(local, fft=args.fft, probe_stride=0, lanes=args.lanes,
-                              pass_threads=args.pass_threads, skip_empty=skip_empty, pitch_pad=args.pitch_pad)
+                              pass_threads=args.pass_threads, skip_empty=skip_empty, pitch_pad=args.pitch_pad, split=args.split)
         eng.set_option("graph", args.graph)
         eng.set_option("walk", args.walk)
         plan = eng.plan(hp, atoms)

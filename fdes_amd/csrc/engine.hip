@@ -49,6 +49,8 @@ struct fdes_ctx {
     int lanes_active = 0; // > 0: run_config only deals to the first n lanes (bench: time a kernel without a co-running lane)
     int lanes = 0;        // configurations in flight at once (own stream + buffers each) in the fused slice loop; 0: by grid size
     int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
+    int split = -1;       // potential / transmission passes (P1'..P4) on a stream of their own, one slice pair ahead of the
+                          // wave's passes (P5, P6): concurrency inside ONE configuration; -1 auto, 0 off, 1 on
     int walk = 1;         // row groups per pass workgroup (2: a pass takes half of the workgroup slots, two lanes' passes share every CU)
     int pitch_pad = -1;   // elements added to every row of the fused loop's grids; -1 auto: 64 from 2048-point rows on
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
@@ -130,6 +132,12 @@ struct fdes_plan {
     size_t probe_used = 0;
     uint64_t fft_calls = 0;
     bool want_ew = false;
+    // split slice loop: the potential chain runs on `vs`, the wave chain on the context's stream
+    bool split = false, tap_mode = false;
+    hipStream_t vs = nullptr;
+    float2* Eb[2] = {nullptr, nullptr};  // band-limited transmission spectra of the pair's two slices (split: two buffers)
+    hipEvent_t evE[2] = {nullptr, nullptr}, evP5[2] = {nullptr, nullptr}, evFork = nullptr, evJoin = nullptr;
+    bool p5_seen[2] = {false, false};
     float2* peer_stage = nullptr;   // landing buffer for another GPU's partial sum (fdes_plan_accumulate_from)
     hipEvent_t peer_ev = nullptr;
     // timing
@@ -327,6 +335,9 @@ int forward_propagation(fdes_plan* pl, int comp = -1)
 PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; a.wg = pl->wg; a.pitch_in = pl->pitchN; a.pitch_out = pl->pitchT; a.walk = owner_ctx(pl)->walk; return a; }
 PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; a.wg = pl->wg; a.pitch_in = pl->pitchT; a.pitch_out = pl->pitchN; a.walk = owner_ctx(pl)->walk; return a; }
 
+// stream of the potential / transmission passes
+hipStream_t vstream(fdes_plan* pl) { return (pl->split && !pl->tap_mode) ? pl->vs : pl->ctx->stream; }
+
 // Potential of the slice PAIR (s0, s0 + 1), s0 even: W = V_s0 + i V_(s0+1) (the deposits are real and the filter
 // G is real and even, so one complex transform carries two slices).  P1' builds the x-spectra of the deposit rows
 // straight from the sorted atom records (no deposit grid), P2 applies the filter in (kx, ky) and sums the species.
@@ -341,11 +352,11 @@ int fused_potential_pair(fdes_plan* pl, int s0)
         a.recs = pl->bins.recs_sorted; a.rowstart = pl->bins.rowstart;
         a.q0 = s0 * pl->nZ;
         a.q1 = (s0 + 1 < pl->p.m3) ? (s0 + 1) * pl->nZ : -1;
-        HIPCHK(c, lds_pass(m1, XF_FWD, MID_ATOMS, XF_NONE, true, a, c->stream));
+        HIPCHK(c, lds_pass(m1, XF_FWD, MID_ATOMS, XF_NONE, true, a, vstream(pl)));
     }
     PassArgs b = pass_y(pl);
     b.in0 = pl->A; b.gtab = pl->GT; b.out = pl->B; b.nspecies = pl->nZ; b.species_stride = pl->gsz;
-    HIPCHK(c, lds_pass(m2, XF_FWD, pl->nZ == 1 ? MID_GTAB : MID_GTABN, XF_INV, true, b, c->stream));
+    HIPCHK(c, lds_pass(m2, XF_FWD, pl->nZ == 1 ? MID_GTAB : MID_GTABN, XF_INV, true, b, vstream(pl)));
     return FDES_OK;
 }
 
@@ -424,14 +435,21 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
         PassArgs a3 = pass_x(pl);
         a3.in0 = pl->B; a3.out = pl->C; a3.out2 = pl->C2; a3.scale = pl->p.imPot;
         a3.band = band; a3.skip_dead_stores = bs;
-        HIPCHK(c, lds_pass(m1, XF_INV, MID_EXPIV_PAIR, XF_FWD, true, a3, c->stream));
+        HIPCHK(c, lds_pass(m1, XF_INV, MID_EXPIV_PAIR, XF_FWD, true, a3, vstream(pl)));
     }
+    const bool split = pl->split && !pl->tap_mode;
+    const int ei = s & 1;
     PassArgs a4 = pass_y(pl);
-    a4.in0 = (s & 1) ? pl->C2 : pl->C; a4.out = pl->E; a4.scale = 1.f / ((float)pl->m12); a4.mindim = md;
+    a4.in0 = (s & 1) ? pl->C2 : pl->C; a4.out = pl->Eb[ei]; a4.scale = 1.f / ((float)pl->m12); a4.mindim = md;
     a4.band = band; a4.live_rows_only = bs;
-    HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, c->stream));
+    if (split && pl->p5_seen[ei]) HIPCHK(c, hipStreamWaitEvent(pl->vs, pl->evP5[ei], 0)); // the wave chain has consumed this buffer
+    HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, vstream(pl)));
+    if (split) {
+        HIPCHK(c, hipEventRecord(pl->evE[ei], pl->vs));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, pl->evE[ei], 0));
+    }
     PassArgs a5 = pass_x(pl);
-    a5.in0 = pl->E; a5.in1 = pl->PSIH; a5.out = pl->F;
+    a5.in0 = pl->Eb[ei]; a5.in1 = pl->PSIH; a5.out = pl->F;
     a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
     // roofline probe: P5 is the longest kernel of the loop; every probe_stride-th launch is bracketed by events
     const int pstride = owner_ctx(pl)->probe_stride;
@@ -449,10 +467,34 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
         a5.ev_stop = ev->b;
     }
     HIPCHK(c, lds_pass(m1, XF_INV, MID_MULPSI, XF_FWD, true, a5, c->stream));
+    if (split) {
+        HIPCHK(c, hipEventRecord(pl->evP5[ei], c->stream));
+        pl->p5_seen[ei] = true;
+    }
     PassArgs a6 = pass_y(pl);
     a6.in0 = pl->F; a6.prow = pl->PT; a6.pcol = pl->PT + m1; a6.mindim = md; a6.out = pl->PSIH;
     a6.band = band; a6.live_rows_only = bs;
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
+    return FDES_OK;
+}
+
+// fork / join of the potential stream around the slices of one configuration (also inside a stream capture, where the
+// event edges become graph dependencies)
+int split_fork(fdes_plan* pl)
+{
+    if (!(pl->split && !pl->tap_mode)) return FDES_OK;
+    fdes_ctx* c = pl->ctx;
+    pl->p5_seen[0] = pl->p5_seen[1] = false;
+    HIPCHK(c, hipEventRecord(pl->evFork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(pl->vs, pl->evFork, 0));
+    return FDES_OK;
+}
+int split_join(fdes_plan* pl)
+{
+    if (!(pl->split && !pl->tap_mode)) return FDES_OK;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipEventRecord(pl->evJoin, pl->vs));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, pl->evJoin, 0));
     return FDES_OK;
 }
 
@@ -510,9 +552,12 @@ int slice_loop(fdes_plan* pl, int nslices)
         fdes_ctx* c = pl->ctx;
         const fdes_ctx* oc = owner_ctx(pl); // lanes follow the owner's runtime options
         const bool timing_probe = (oc->probe_stride > 0);
-        if (!oc->opt_graph || timing_probe || nslices < 1) {
+        // the two-stream loop is issued directly: captured, its cross-stream edges cost 5 % (12.2 k against 12.85 k)
+        if (!oc->opt_graph || timing_probe || nslices < 1 || pl->split) {
             RC(fused_enter(pl));
+            RC(split_fork(pl));
             for (int s = 0, adv = 1; s < nslices; s += adv) RC(fused_slice(pl, s, nslices, &adv));
+            RC(split_join(pl));
             return fused_leave(pl, nslices > 0);
         }
         // key: slice count, band option and the empty-slice pattern (FNV-1a over one bit per slice)
@@ -525,6 +570,7 @@ int slice_loop(fdes_plan* pl, int nslices)
         for (int b = 0; b < 4; b++) pattern.push_back((uint8_t)((unsigned)nslices >> (8 * b)));
         pattern.push_back((uint8_t)oc->band_skip);
         pattern.push_back((uint8_t)oc->walk);
+        pattern.push_back((uint8_t)(pl->split ? 1 : 0));
         pattern.push_back(pl->seg_h.empty() ? 0 : 1);
         if (!pl->seg_h.empty())
             for (int q = 0; q < pl->p.m3; q++) pattern.push_back(pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ] ? 2 : 3);
@@ -541,7 +587,9 @@ int slice_loop(fdes_plan* pl, int nslices)
             int rc = FDES_OK;
             if (e == hipSuccess) {
                 rc = fused_enter(pl);
+                if (rc == FDES_OK) rc = split_fork(pl);
                 for (int s = 0, adv = 1; s < nslices && rc == FDES_OK; s += adv) rc = fused_slice(pl, s, nslices, &adv);
+                if (rc == FDES_OK) rc = split_join(pl);
                 if (rc == FDES_OK) rc = fused_leave(pl, true);
             }
             hipGraph_t graph = nullptr;
@@ -668,6 +716,18 @@ void report_progress(fdes_plan* pl, int64_t issued, int64_t total_configs, bool 
     c->progress(c->progress_user, done * (int64_t)pl->p.m3, total_configs * (int64_t)pl->p.m3);
 }
 
+// Configurations a plan keeps in flight: lanes hide the gap between dependent kernels of one stream - three up to 1024^2,
+// where the kernels are no longer than that gap, two above - but never more than the job has configurations (n3 x
+// frozen-phonon configurations): a single image gets one lane, and its concurrency from the split slice loop instead.
+int plan_lanes(const fdes_ctx* c, const fdes_plan* pl)
+{
+    if (c->is_lane_ctx) return 1;
+    if (c->lanes > 0) return c->lanes;
+    const long total = (long)pl->p.n3 * (long)(pl->p.frPh > 0 ? pl->p.frPh : 1);
+    const int by_size = (pl->fused && pl->m12 <= (size_t)1024 * 1024) ? 3 : 2;
+    return (int)(total < by_size ? total : by_size);
+}
+
 int check_params(fdes_ctx* ctx, const fdes_params* p, const fdes_atoms* a)
 {
     if (!p || !a || !p->tiltspec || !p->tiltbeam || !p->defoci) { ctx->err = "null parameter / atom pointers"; return FDES_EINVAL; }
@@ -775,6 +835,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
     if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "split")) { if (value < -1 || value > 1) return FDES_EINVAL; c->split = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "walk")) { if (value < 1 || value > 8) return FDES_EINVAL; c->walk = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "pitch_pad")) { if (value < -1 || value > 1024 || (value > 0 && value % 2)) return FDES_EINVAL; c->pitch_pad = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
@@ -812,6 +873,11 @@ int fdes_plan_destroy(fdes_plan* pl)
     for (auto& e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : pl->probe) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (pl->peer_ev) (void)hipEventDestroy(pl->peer_ev);
+    if (pl->split) {
+        if (pl->vs) { (void)hipStreamSynchronize(pl->vs); (void)hipStreamDestroy(pl->vs); }
+        for (hipEvent_t e : {pl->evE[0], pl->evE[1], pl->evP5[0], pl->evP5[1], pl->evFork, pl->evJoin}) if (e) (void)hipEventDestroy(e);
+        for (void* q : {(void*)pl->Eb[1], (void*)pl->B, (void*)pl->F}) if (q) (void)hipFree(q);
+    }
     fdes_params_release(&pl->p0);
     delete pl;
     return FDES_OK;
@@ -948,13 +1014,30 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             const size_t gn = (size_t)pl->pitchN * (size_t)m2, gt = (size_t)pl->pitchT * (size_t)m1;
             pl->gsz = gn > gt ? gn : gt;
         }
+        // split: the potential chain of the next slice pair runs beside the wave chain of this one, so the buffers that
+        // one stream shares between its own consecutive passes stay aliased (A and C) and those that cross streams do
+        // not (B, two E, F): 7 grids per lane instead of 4
+        pl->split = c->split > 0 || (c->split < 0 && plan_lanes(c, pl) == 1);
         PLCHK(dmalloc(c, &pl->C, pl->gsz));
-        pl->F = pl->C;
+        if (pl->split) PLCHK(dmalloc(c, &pl->F, pl->gsz)); else pl->F = pl->C;
         if (pl->nZ == 1) pl->A = pl->C;
         else PLCHK(dmalloc(c, &pl->A, pl->gsz * (size_t)pl->nZ));
         PLCHK(dmalloc(c, &pl->C2, pl->gsz)); // x-spectrum of the transmission function of the pair's second slice
         PLCHK(dmalloc(c, &pl->E, pl->gsz));
-        pl->B = pl->E; // the packed pair potential is consumed by P3 before P4 writes E
+        pl->Eb[0] = pl->Eb[1] = pl->E;
+        if (pl->split) {
+            PLCHK(dmalloc(c, &pl->Eb[1], pl->gsz));
+            PLCHK(dmalloc(c, &pl->B, pl->gsz));
+            PLHIP(hipMemsetAsync(pl->Eb[1], 0, sizeof(float2) * pl->gsz, c->stream));
+            PLHIP(hipMemsetAsync(pl->F, 0, sizeof(float2) * pl->gsz, c->stream));
+            // same priority as the wave stream: with a priority class of its own (greatest or least) the captured graph
+            // of the two-stream loop runs at half the rate (6.2 k against 12.2 k slice-propagations/s at 2048^2)
+            PLHIP(hipStreamCreateWithFlags(&pl->vs, hipStreamNonBlocking));
+            for (hipEvent_t* e : {&pl->evE[0], &pl->evE[1], &pl->evP5[0], &pl->evP5[1], &pl->evFork, &pl->evJoin})
+                PLHIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        } else {
+            pl->B = pl->E; // the packed pair potential is consumed by P3 before P4 writes E
+        }
         PLCHK(dmalloc(c, &pl->PSIH, pl->gsz));
         if (c->share_PT) { pl->PT = c->share_PT; pl->GT = c->share_GT; pl->tables_shared = true; }
         else {
@@ -979,14 +1062,14 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     // above (a third lane only thrashes the Infinity Cache at 2048^2; equal priorities there: a high-priority lane
     // starves the other one of workgroup slots, -1.5 %).
     // (the rocFFT path stays at two: with three prioritised lanes it drops from 9.2 k to 3.6 k slices/s at 800^2)
-    const int nlanes = c->lanes > 0 ? c->lanes : ((pl->fused && pl->m12 <= (size_t)1024 * 1024) ? 3 : 2);
+    const int nlanes = plan_lanes(c, pl);
     if (nlanes > 1 && !c->is_lane_ctx) {
         for (int l = 1; l < nlanes; l++) {
             fdes_ctx* lc = nullptr;
             PLCHK(create_ctx(&lc, c->device, nlanes >= 3 ? (l <= 2 ? l : 0) : 0));
             lc->is_lane_ctx = true;
             // frozen here: fft, lanes, pass_threads (they shape the lane plan); the others are read through owner_ctx()
-            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad;
+            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad; lc->split = pl->split ? 1 : 0;
             lc->share_PT = pl->PT; lc->share_GT = pl->GT; // read-only tables of the parent plan (built and synchronised above)
             pl->lane_ctx.push_back(lc);
             fdes_plan* lp = nullptr;
@@ -1109,7 +1192,8 @@ int fdes_plan_sync(fdes_plan* pl)
 {
     if (!pl) return FDES_EINVAL;
     HIPCHK(pl->ctx, hipSetDevice(pl->ctx->device));
-    for (fdes_plan* l : pl->lanes) HIPCHK(pl->ctx, hipStreamSynchronize(l->ctx->stream));
+    for (fdes_plan* l : pl->lanes) { if (l->vs) HIPCHK(pl->ctx, hipStreamSynchronize(l->vs)); HIPCHK(pl->ctx, hipStreamSynchronize(l->ctx->stream)); }
+    if (pl->vs) HIPCHK(pl->ctx, hipStreamSynchronize(pl->vs));
     HIPCHK(pl->ctx, hipStreamSynchronize(pl->ctx->stream));
     return FDES_OK;
 }
@@ -1290,7 +1374,10 @@ int fdes_plan_tap_potential(fdes_plan* pl, int k, int j, int s, float* V)
     RC(config_atoms(pl, k, j < 0 ? 0 : j));
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
     if (pl->fused) {
-        RC(fused_potential_pair(pl, s & ~1));
+        pl->tap_mode = true; // everything on the context's stream
+        const int rcp = fused_potential_pair(pl, s & ~1);
+        pl->tap_mode = false;
+        RC(rcp);
         PassArgs a = pass_x(pl);
         a.in0 = pl->B; a.out = pl->T; a.pitch_out = 0;
         HIPCHK(c, lds_pass(pl->p.m1, XF_INV, MID_NONE, XF_NONE, false, a, c->stream));

@@ -239,7 +239,12 @@ int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_
  *   "lanes_active"  n > 0: run_config deals only to the first n lanes from now on (0: all)
  *   "lanes"      1..4 configurations in flight at once in the fused slice loop (default 2): run_config calls are
  *                dealt round-robin to lanes, partial intensity sums are folded in end_measurement
- *   "pass_threads"  0 auto, 256 or 512 threads per LDS-pass workgroup                        */
+ *   "pass_threads"  0 auto, 256 or 512 threads per LDS-pass workgroup
+ *   "split"      -1 (default): a plan with one lane (single-image jobs; a plan never has more lanes than the job has
+ *                configurations) runs the potential / transmission passes of its slice loop on a second stream, one
+ *                slice pair ahead of the wave's passes; 0 never, 1 always
+ *   "pitch_pad"  -1 (default: 64 from 2048-point rows on) elements of padding per row of the slice loop's grids
+ *   "walk"       1 (default) .. 8: launch every pass in that many parts                                  */
 int fdes_set_option(fdes_ctx* ctx, const char* key, int64_t value);
 
 /* Progress report.  The reference prints a percentage to stderr from inside its slice loop (progressCounter,

@@ -240,13 +240,15 @@ def test_options_set_after_plan_creation_reach_every_lane(oracle):
 
 @pytest.mark.parametrize("m", [256, 2048])
 def test_layout_and_launch_options_do_not_change_a_bit(m):
-    """Row padding (`pitch_pad`) and split launches (`walk`) change where data lives and how a pass is launched, not what
-    is computed: the exit wave must be bit-identical to the dense, whole-launch run."""
+    """Row padding (`pitch_pad`), split launches (`walk`) and the potential chain on a stream of its own (`split`) change
+    where data lives and how and when a pass is launched, not what is computed: the exit wave must be bit-identical to
+    the dense, whole-launch, one-stream run."""
     hp, at = S.case_tiny(m=m, m3=5, nz=2, nat=200, tilt=True, seed=71)
     fdes_amd.consistent(hp)
     waves = {}
-    for key, opts in {"dense": dict(pitch_pad=0, walk=1), "padded": dict(pitch_pad=64, walk=1), "odd pad": dict(pitch_pad=136, walk=1),
-                      "split": dict(pitch_pad=64, walk=2), "quarters": dict(pitch_pad=0, walk=4)}.items():
+    for key, opts in {"dense": dict(pitch_pad=0, walk=1, split=0), "padded": dict(pitch_pad=64, walk=1), "odd pad": dict(pitch_pad=136, walk=1),
+                      "split": dict(pitch_pad=64, walk=2), "quarters": dict(pitch_pad=0, walk=4),
+                      "two streams": dict(split=1), "two streams, no graph": dict(split=1, graph=0), "one stream": dict(split=0)}.items():
         eng = fdes_amd.Engine(0, skip_empty=0, **opts)
         pl = eng.plan(hp, at)
         waves[key] = pl.tap_wave(0, 0)
