@@ -83,6 +83,41 @@ def test_c5_grid_engine_default_with_empty_slices(oracle):
     check(img, ref, None, 1e-5, "C5 grid image, engine defaults")
 
 
+def test_c5_full_specimen(oracle):
+    """BASELINE config 5 itself: Au cuboctahedron k = 60 (738 221 atoms), 4096^2 wave, 512 slices, frozen phonons.  (1) the
+    wave after the first 20 slices (the particle begins at slice 12) of configuration (0, 0) - the densest binning the engine sees: 1 440 atoms per slice -
+    against the float32 / float64 oracle; (2) one configuration through all 512 slices on both launch sequences (every
+    slice the full sequence / runs of empty slices as one P^n step): finite, normalised (no absorption: mean 1 up to the
+    aperture), and equal to each other within the float32 error of 512 slices."""
+    hp, at = S.case_c5()
+    fdes_amd.consistent(hp)
+    assert (hp.c.m1, hp.c.m3, hp.c.frPh, at.n) == (4096, 512, 16, 738221)
+    q, _ = oracle.sub_sliced(hp)
+    imgs = {}
+    for skip in (0, 1):
+        eng = fdes_amd.Engine(0, skip_empty=skip)
+        pl = eng.plan(hp, at)
+        if skip == 0:
+            psi = pl.tap_wave(0, 0, 20)
+            ref = oracle.wave(q, at, 0, 0, nslices=20, prec="f64")
+            check(psi, ref, oracle.wave(q, at, 0, 0, nslices=20, prec="f32"), 1e-5, "C5 specimen, wave after 20 slices")
+            assert np.abs(ref - 1).max() > 0.1   # the particle has begun
+        pl.begin_measurement(0)
+        pl.run_config(0, 0, 1.0)
+        pl.end_measurement(0)
+        imgs[skip] = pl.get_images()[0].astype(np.float64)
+        pl.close()
+        eng.close()
+    for skip, img in imgs.items():
+        assert np.isfinite(img).all()
+        print(f"[parity] C5 full depth, skip_empty={skip}: image mean {img.mean():.6f} min {img.min():.4f} max {img.max():.4f}")
+        assert 0.7 < img.mean() < 1.02 and img.min() >= 0
+    e = relerr(imgs[1], imgs[0])
+    print(f"[parity] C5 full depth: P^n runs vs full sequence on every slice: {e:.3e}")
+    assert e < 1e-4
+    assert imgs[0].std() / imgs[0].mean() > 0.05
+
+
 def test_c4_full_series(oracle):
     """BASELINE config 4 at full series length: 64 beam tilts x 8 frozen-phonon configurations, SrTiO3 9x9x20 cells
     (8 100 atoms, three species), 1024^2 wave, 40 slices = 20 480 slice-propagations through three lanes and graph
