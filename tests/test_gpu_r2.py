@@ -46,6 +46,29 @@ def test_fused_slice_loop_every_geometry(oracle, m, threads, nz):
     eng.close()
 
 
+@pytest.mark.parametrize("kw", [dict(m=2048, rect=True, m3=4, nz=2, nat=300, tilt=True), dict(m=4096, rect=True, m3=3, nz=1, nat=300),
+                                dict(m=2048, rect=True, m3=5, nz=2, nat=200, frPh=3, mode=1, beam_tilt=True)])
+def test_rectangular_grids_with_padded_rows(oracle, kw):
+    """2048 x 1024 and 4096 x 2048 grids: the two row lengths of the fused loop differ, rows are padded (pitch_pad 64
+    from 2048 points on) and the band-limit bookkeeping is off (it assumes a square grid): exit wave / image against the
+    float64 oracle, on the one-lane two-stream loop and on lanes + graph replay."""
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
+    assert hp.c.m1 == 2 * hp.c.m2
+    eng = fdes_amd.Engine(0)
+    if kw.get("frPh", 0) > 0:
+        img = eng.build_measurements(hp, at)["image"]
+        check(img, oracle.build_measurements(hp, at, prec="f64")["image"], None, 1e-5, f"rectangular image {kw}")
+    else:
+        q, _ = oracle.sub_sliced(hp)
+        pl = eng.plan(hp, at)
+        assert pl.fft_backend() == 2
+        psi = pl.tap_wave(0, 0)
+        check(psi, oracle.wave(q, at, 0, 0, prec="f64"), None, 1e-5, f"rectangular exit wave {kw}")
+        pl.close()
+    eng.close()
+
+
 @pytest.mark.parametrize("threads,band_skip", [(0, 1), (512, 0)])
 def test_c5_grid_slice_loop_against_oracle(oracle, threads, band_skip):
     """BASELINE config 5's grid (4096^2): the 512-thread / 136 KiB pass geometry (MID_ATOMS, MID_GTABN, MID_EXPIV_PAIR,
