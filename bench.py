@@ -294,6 +294,20 @@ def run_extras(device):
                                 "frac": round(ENGINE_BYTES_PER_PX_SLICE * px * rate / 8e12, 4)}}
     pl.close()
     eng.close()
+    # the boundary call itself with HOST buffers (fdes_build_measurements: atoms in over PCIe, plan creation, tables,
+    # 8 frozen-phonon configurations of the headline specimen, detector chain, image out over PCIe): the PCIe- and
+    # setup-inclusive rate, never the headline
+    hp, at = specimens.case_c3(frPh=8)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(device, skip_empty=0)
+    eng.build_measurements(hp, at)   # first call: code objects, rocPRIM temporaries
+    t0 = time.perf_counter()
+    img = eng.build_measurements(hp, at)["image"]
+    dt = time.perf_counter() - t0
+    eng.close()
+    out["end_to_end_host_buffers"] = {"workload": f"fdes_build_measurements, C3 specimen ({at.n} atoms), 2048x2048 wave, 256 slices, 8 configurations, "
+                                                  "host pointers in and out", "seconds": round(dt, 4),
+                                      "value": round(8 * 256 / dt, 1), "unit": "slice-propagations/s", "finite": bool(np.isfinite(img).all())}
     # SURVEY 8d micro-benchmark: psi <- F^-1[P F[t psi]] on device-resident random psi and unit-modulus t, one stream,
     # 256 units; priced with the survey's fixed 80 B/px model
     out["propagation_unit"] = {}
