@@ -29,6 +29,13 @@ namespace fdes {
 
 namespace {
 
+#ifndef FDES_EXP_NOVALU
+#define FDES_EXP_NOVALU 0 // timing experiments only (results are garbage): transforms without arithmetic / without LDS exchanges
+#endif
+#ifndef FDES_EXP_NOLDS
+#define FDES_EXP_NOLDS 0
+#endif
+
 constexpr float C1 = 0.923879532511286756f; // cos(pi/8)
 constexpr float S1 = 0.382683432365089772f; // sin(pi/8)
 constexpr float C2 = 0.707106781186547524f; // cos(pi/4)
@@ -340,8 +347,11 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
     constexpr int NW = (T + 63) / 64;
     const int rd0 = t + (t >> 4); // read base: padi(t)
     // ---- stage 0
+#if !FDES_EXP_NOVALU
 #pragma unroll
     for (int h = 0; h < WGeo<WG>::NRV; h++) r16<INV>(a[h]);
+#endif
+#if !FDES_EXP_NOVALU
     {
         float2 wp[16];
         if constexpr (TWR == TWM_POW) tw_powers(tw.b0, wp);
@@ -352,6 +362,8 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
             for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul<INV>(a[h][k], w);
         }
     }
+#endif
+#if !FDES_EXP_NOLDS
     if (WAR0) group_sync<NW>(gs);
 #pragma unroll
     for (int h = 0; h < WGeo<WG>::NRV; h++) {
@@ -366,11 +378,15 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
 #pragma unroll
         for (int l = 0; l < 16; l++) a[h][l] = row[rd0 + (T + T / 16) * l]; // padi(t + T l): T is a multiple of 16
     }
+#endif
     // ---- stage 1
+#if !FDES_EXP_NOVALU
 #pragma unroll
     for (int h = 0; h < WGeo<WG>::NRV; h++) r16<INV>(a[h]);
+#endif
     if constexpr (G_::R3 > 1) {
         const int q = t & 15, p = t >> 4;
+#if !FDES_EXP_NOVALU
         float2 wp[16];
         if constexpr (TWR == TWM_POW) tw_powers(tw.b1, wp);
 #pragma unroll
@@ -379,6 +395,8 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
 #pragma unroll
             for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul<INV>(a[h][k], w);
         }
+#endif
+#if !FDES_EXP_NOLDS
         group_sync<NW>(gs);
 #pragma unroll
         for (int h = 0; h < WGeo<WG>::NRV; h++) {
@@ -393,7 +411,9 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
 #pragma unroll
             for (int l = 0; l < 16; l++) a[h][l] = row[rd0 + (T + T / 16) * l]; // padi(t + T l): T is a multiple of 16
         }
+#endif
         // ---- stage 2: G butterflies of radix R3 over registers {i + G j}
+#if !FDES_EXP_NOVALU
 #pragma unroll
         for (int h = 0; h < WGeo<WG>::NRV; h++) {
             if constexpr (G_::R3 == 2) {
@@ -410,6 +430,7 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
                 r16<INV>(a[h]);
             }
         }
+#endif
     }
 }
 
