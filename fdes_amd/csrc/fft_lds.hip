@@ -54,6 +54,36 @@ __device__ __forceinline__ cf cmul(cf a, cf b) { return __builtin_elementwise_fm
 __device__ __forceinline__ cf cmulc(cf a, cf b) { return __builtin_elementwise_fma(a.yx, cf{b.y, -b.y}, a * b.xx); }
 // multiply by the forward twiddle w (INV = false) or its conjugate (INV = true)
 template <bool INV> __device__ __forceinline__ float2 twmul(float2 a, float2 w) { return INV ? cmulc(a, w) : cmul(a, w); }
+// The same products for a factor that is only known at run time (stage twiddles, table values, the second operand of a
+// product).  The compiler cannot put the sign of ONE half of (-b.y, b.y) into the instruction's neg_lo / neg_hi modifier
+// and builds that vector in registers instead (v_xor + 2 v_mov per factor: 290 of P5's 2460 vector instructions); with
+// the modifier written out a product is the two packed instructions it should be.  Same operations, same rounding.
+#ifndef FDES_ASM_CMUL
+#define FDES_ASM_CMUL 1
+#endif
+__device__ __forceinline__ cf cmul_rt(cf a, cf b)
+{
+#if FDES_ASM_CMUL
+    const cf t = a * b.xx;
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+#else
+    return cmul(a, b);
+#endif
+}
+__device__ __forceinline__ cf cmulc_rt(cf a, cf b)
+{
+#if FDES_ASM_CMUL
+    const cf t = a * b.xx;
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+#else
+    return cmulc(a, b);
+#endif
+}
+template <bool INV> __device__ __forceinline__ float2 twmul_rt(float2 a, float2 w) { return INV ? cmulc_rt(a, w) : cmul_rt(a, w); }
 // multiply by -i (forward) / +i (inverse)
 template <bool INV> __device__ __forceinline__ float2 mul_mi(float2 a) { return a.yx * (INV ? cf{-1.f, 1.f} : cf{1.f, -1.f}); }
 // b + (-i) a (forward) / b + i a (inverse), and b - (...): one packed fma each, the swap rides on op_sel
@@ -76,7 +106,7 @@ __device__ __forceinline__ float2 cmul3(float2 f0, float2 f1)
     c *= b - a;
     return make_float2(k - d, k + c);
 #else
-    return cmul(f0, f1);
+    return cmul_rt(f0, f1);
 #endif
 }
 
@@ -336,7 +366,7 @@ __device__ __forceinline__ void tw_powers(const cf (&b)[6], cf (&w)[16])
 #pragma unroll
     for (int h = 0; h < 3; h++)
 #pragma unroll
-        for (int l = 0; l < 3; l++) w[4 * (h + 1) + l + 1] = cmul(hi[h], lo[l]);
+        for (int l = 0; l < 3; l++) w[4 * (h + 1) + l + 1] = cmul_rt(hi[h], lo[l]);
 }
 template <int N, int WG, bool INV, bool WAR0, int TWR>
 __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* __restrict__ lds, const int r, const int t, const Tw& tw,
@@ -359,7 +389,7 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
         for (int k = 1; k < 16; k++) {
             const float2 w = TWR == TWM_POW ? wp[k] : (TWR == TWM_REGS ? tw.r0[k] : tw.g0[k * T + t]);
 #pragma unroll
-            for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul<INV>(a[h][k], w);
+            for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul_rt<INV>(a[h][k], w);
         }
     }
 #endif
@@ -393,7 +423,7 @@ __device__ __forceinline__ void row_fft(float2 (&a)[WGeo<WG>::NRV][16], float2* 
         for (int k = 1; k < 16; k++) {
             const float2 w = TWR == TWM_POW ? wp[k] : (TWR == TWM_REGS ? tw.r1[k] : tw.g1[k * (T / 16) + p]);
 #pragma unroll
-            for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul<INV>(a[h][k], w);
+            for (int h = 0; h < WGeo<WG>::NRV; h++) a[h][k] = twmul_rt<INV>(a[h][k], w);
         }
 #endif
 #if !FDES_EXP_NOLDS
@@ -477,23 +507,33 @@ __device__ __forceinline__ void load_rows(float2 (&a)[WGeo<WG>::NRV][16], const 
     // `band` is uniform.  The straddling blocks are common code for both settings (the flag only feeds the select),
     // the dead blocks are loads under a uniform branch: written as two whole variants under one `if`, the compiler
     // waited for the straddling loads inside the branch, one HBM round trip before the other 28 loads were issued.
+    // Addresses: uniform base (scalar registers) + a 32-bit byte offset per thread + an immediate.  Written as element
+    // indices the compiler widens every index to 64 bits (one v_add_u32 and one v_lshl_add_u64 per load); as byte offsets
+    // one 32-bit add serves the GS loads whose immediates fit the instruction's 12 bits.
+    constexpr int GS = 4095 / (T * 8) + 1;
+    const char* __restrict__ sb = reinterpret_cast<const char*>(src);
+    auto at = [&](unsigned off, int imm) -> float2 { return *reinterpret_cast<const float2*>(sb + off + imm); };
 #pragma unroll
-    for (int h = 0; h < WGeo<WG>::NRV; h++)
+    for (int h = 0; h < WGeo<WG>::NRV; h++) {
+        const unsigned b0 = (rbase[h] + (unsigned)t) * 8u;
 #pragma unroll
         for (int l = 0; l < 16; l++) {
             const int lo = T * l, hi = T * l + T - 1;
             const int cls = (hi <= LB || lo >= N - LB) ? 0 : ((lo > LB && hi < N - LB) ? 1 : 2);
-            if (cls == 0) a[h][l] = src[rbase[h] + t + T * l];
+            const unsigned bj = b0 + (unsigned)((l / GS) * GS * T * 8);
+            const int imm = (l % GS) * T * 8;
+            if (cls == 0) a[h][l] = at(bj, imm);
             else if (cls == 1) {
                 a[h][l] = make_float2(0.f, 0.f);
-                if (!band) a[h][l] = src[rbase[h] + t + T * l];
+                if (!band) a[h][l] = at(bj, imm);
             } else {
                 const int c = t + T * l;
                 const bool dd = band && c > LB && c < N - LB;
-                const float2 v = src[rbase[h] + (dd ? t : c)];
+                const float2 v = at(dd ? b0 : bj + (unsigned)imm, 0);
                 a[h][l] = dd ? make_float2(0.f, 0.f) : v;
             }
         }
+    }
 }
 
 // In-kernel stamps (diagnostic build only, -DFDES_STAMPS; no stamp executes in the product): lane 0 of every wave
@@ -514,12 +554,12 @@ __device__ __forceinline__ void load_rows(float2 (&a)[WGeo<WG>::NRV][16], const 
 #define STAMP(slot, WAITV) do { } while (0)
 #endif
 
+// The body of a pass for the workgroup blockIdx.x + A.vb0 of A.nvirt.
 template <int N, int WG, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) void k_pass(PassArgs A)
+__device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict__ lds)
 {
     using G_ = Geo<N, WG>;
     constexpr int T = G_::T, R = G_::R, RH = G_::RH;
-    extern __shared__ float2 lds[];
     STAMP(0, false);
     STAMP(15, false); // wall clock (100 MHz) of the same instant
     constexpr bool TWREG = !FDES_NO_TWR && (pass_waves(MID) == 2) && (WGeo<WG>::NRV == 2) && (MID != MID_MULPSI && (MID != MID_PTAB || FDES_PTAB_TWR) && MID != MID_GTABN && (MID != MID_EXPIV_PAIR || (FDES_PAIR_TWR && N <= 2048)));
@@ -595,7 +635,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
     const float2* __restrict__ in1 = A.in1 ? reinterpret_cast<const float2*>(A.in1) + gbase : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
     float2* __restrict__ zsrc = A.zsrc ? reinterpret_cast<float2*>(A.zsrc) + gbase : nullptr;
-    if constexpr (MID == MID_ATOMS) A.out += (size_t)blockIdx.y * A.species_stride; // one launch covers every species
+    float2* const out0 = reinterpret_cast<float2*>(A.out) + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0); // MID_ATOMS: one launch covers every species
 
     float2 a[WGeo<WG>::NRV][16];
     float2 b[(MID == MID_MULPSI) ? WGeo<WG>::NRV : 1][16]; // second operand
@@ -652,7 +692,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
 #pragma unroll
                     for (int it = 0; it < WGeo<WG>::NRV * 16; it++) {
                         const int e = it * WGeo<WG>::THR + tid;
-                        (reinterpret_cast<float2*>(A.out) + row0)[(unsigned)(e / R) * ldt + (unsigned)(e & (R - 1))] = make_float2(0.f, 0.f);
+                        (out0 + row0)[(unsigned)(e / R) * ldt + (unsigned)(e & (R - 1))] = make_float2(0.f, 0.f);
                     }
                 }
                 return;
@@ -872,7 +912,7 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
     STAMP(6, false); // point-wise work done
     xform<N, WG, POST, (PRE != XF_NONE), TWR>(a, lds, r, t, tw, gs);
     STAMP(7, false); // last transform done
-    store_rows(a, reinterpret_cast<float2*>(A.out));
+    store_rows(a, out0);
     STAMP(8, false); // stores issued
     STAMP(9, true);  // stores drained
     if constexpr (MID == MID_EXPIV_PAIR) {
@@ -885,6 +925,13 @@ __global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) vo
         xform<N, WG, POST, true, TWR>(a, lds, r, t, tw, gs);
         store_rows(a, reinterpret_cast<float2*>(A.out2));
     }
+}
+
+template <int N, int WG, int PRE, int MID, int POST, bool STORE_T>
+__global__ __launch_bounds__(WGeo<WG>::THR, ((WG & 1) ? 4 : pass_waves(MID))) void k_pass(PassArgs A)
+{
+    extern __shared__ float2 lds[];
+    pass_body<N, WG, PRE, MID, POST, STORE_T>(A, lds);
 }
 
 #undef float2
