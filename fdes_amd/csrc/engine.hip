@@ -1007,8 +1007,10 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // lanes at 2048^2 (304 MiB) mostly stay inside the 256 MiB Infinity Cache.  Dead (band-limited) rows of C / F
         // may hold stale data of the other tenant: P4 / P6 never read them.
         {
-            // measured: 4096^2 +30 % (C5 2231 -> 2898 slice-propagations/s), 2048^2 +1.4 %; 8 or 16 elements are worse than none
-            const int pad = c->pitch_pad >= 0 ? c->pitch_pad : ((m1 >= 2048 || m2 >= 2048) ? 64 : 0);
+            // measured: 4096^2 +30 % with 64 elements (C5 2231 -> 2898 slice-propagations/s; 96 ... 320 equal, 32 as bad as
+            // none); 2048^2 +1.4 % with 64, +2.7 % with 32 (six of seven A/B rounds); 8 or 16 elements are worse than none
+            const int big = m1 > m2 ? m1 : m2;
+            const int pad = c->pitch_pad >= 0 ? c->pitch_pad : (big >= 4096 ? 64 : (big >= 2048 ? 32 : 0));
             pl->pitchN = m1 + pad;
             pl->pitchT = m2 + pad;
             const size_t gn = (size_t)pl->pitchN * (size_t)m2, gt = (size_t)pl->pitchT * (size_t)m1;

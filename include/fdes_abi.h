@@ -243,7 +243,7 @@ int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_
  *   "split"      -1 (default): a plan with one lane (single-image jobs; a plan never has more lanes than the job has
  *                configurations) runs the potential / transmission passes of its slice loop on a second stream, one
  *                slice pair ahead of the wave's passes; 0 never, 1 always
- *   "pitch_pad"  -1 (default: 64 from 2048-point rows on) elements of padding per row of the slice loop's grids
+ *   "pitch_pad"  -1 (default: 32 for 2048-point rows, 64 from 4096 on) elements of padding per row of the slice loop's grids
  *   "walk"       1 (default) .. 8: launch every pass in that many parts                                  */
 int fdes_set_option(fdes_ctx* ctx, const char* key, int64_t value);
 
