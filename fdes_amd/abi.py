@@ -176,6 +176,7 @@ PROTOTYPES = [
     ("fdes_plan_lanes", C.c_int, [_vp]),
     ("fdes_plan_num_slices", C.c_int, [_vp]),
     ("fdes_plan_slices_done", C.c_int64, [_vp]),
+    ("fdes_plan_empty_queries", C.c_int64, [_vp]),
     ("fdes_plan_slice_loop_ms", C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
     ("fdes_plan_probe_ms", C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
     ("fdes_plan_tap_coords", C.c_int, [_vp, C.c_int, C.c_int, _P(C.c_float)]),

@@ -301,6 +301,9 @@ class Plan:
     def slices_done(self):
         return int(self.lib.fdes_plan_slices_done(self.h))
 
+    def empty_queries(self):
+        return int(self.lib.fdes_plan_empty_queries(self.h))
+
     def tap_coords(self, k, j):
         out = np.zeros((self.atoms.n, 3), np.float32)
         self._c(self.lib.fdes_plan_tap_coords(self.h, k, j, fptr(out)))

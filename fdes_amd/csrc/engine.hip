@@ -46,6 +46,12 @@ struct fdes_ctx {
     float* share_GT = nullptr;
     int band_skip = 1;    // do not move / transform the rows and columns the 2/3 band limit zeroes anyway
     int skip_empty = 1;   // slices without atoms: t = 1, only the Fresnel step is applied (fused loop)
+    // skip_empty bookkeeping of the owner context: configurations in a row in which no slice was empty, configurations seen.
+    // A dense specimen (a crystal that fills the box) never has an empty slice: after kDenseAfter such configurations the
+    // per-configuration question (one D2H of the segment table and one host wait on the lane's stream) is only asked every
+    // kDenseRecheck-th configuration; meanwhile every slice takes the full sequence, which is always correct.
+    int dense_streak = 0;
+    int64_t cfg_seen = 0, empty_queries = 0;
     int lanes_active = 0; // > 0: run_config only deals to the first n lanes (bench: time a kernel without a co-running lane)
     int lanes = 0;        // configurations in flight at once (own stream + buffers each) in the fused slice loop; 0: by grid size
     int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
@@ -256,11 +262,20 @@ int config_atoms(fdes_plan* pl, int k, int j)
         HIPCHK(c, hipMemcpyAsync(pl->xyzFP_d, pl->xyzK_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, c->stream));
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
     HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, pl->fused, c->stream));
-    if (pl->fused && owner_ctx(pl)->skip_empty) {
+    fdes_ctx* oc = pl->parent_ctx ? pl->parent_ctx : pl->ctx;
+    constexpr int kDenseAfter = 8, kDenseRecheck = 64;
+    bool ask = pl->fused && oc->skip_empty;
+    if (ask && oc->dense_streak >= kDenseAfter && (oc->cfg_seen % kDenseRecheck) != 0) ask = false;
+    oc->cfg_seen++;
+    if (ask) {
         // which slices hold atoms decides the launch sequence: one small D2H per configuration
         pl->seg_h.resize((size_t)pl->p.m3 * pl->nZ + 1);
         HIPCHK(c, hipMemcpyAsync(pl->seg_h.data(), pl->bins.seg, sizeof(int) * pl->seg_h.size(), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        oc->empty_queries++;
+        bool any_empty = false;
+        for (int q = 0; q < pl->p.m3 && !any_empty; q++) any_empty = pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ];
+        oc->dense_streak = any_empty ? 0 : oc->dense_streak + 1;
     } else {
         pl->seg_h.clear();
     }
@@ -1213,6 +1228,8 @@ int fdes_plan_get_images(fdes_plan* pl, float* image)
 int fdes_plan_fft_backend(const fdes_plan* pl) { return pl ? pl->fft->backend : FDES_EINVAL; }
 int fdes_plan_lanes(const fdes_plan* pl) { return pl ? (int)pl->lanes.size() + 1 : FDES_EINVAL; }
 int fdes_plan_num_slices(const fdes_plan* pl) { return pl ? pl->p.m3 : FDES_EINVAL; }
+int64_t fdes_plan_empty_queries(const fdes_plan* pl) { return pl ? owner_ctx(pl)->empty_queries : 0; }
+
 int64_t fdes_plan_slices_done(const fdes_plan* pl)
 {
     if (!pl) return 0;

@@ -191,6 +191,9 @@ int fdes_plan_lanes(const fdes_plan* plan);
 /* Number of (sub-)slices m3 after sub-slicing; slice-propagations done so far. */
 int fdes_plan_num_slices(const fdes_plan* plan);
 int64_t fdes_plan_slices_done(const fdes_plan* plan);
+/* How many configurations have been asked which of their slices are empty (option "skip_empty": one D2H and one host
+ * wait each); a specimen without empty slices stops being asked after eight configurations in a row (diagnostic). */
+int64_t fdes_plan_empty_queries(const fdes_plan* plan);
 /* Mean device time [ms] of the slice loops between the HIP events recorded by
  * run_config since the last call (measurement). Synchronises. */
 int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);

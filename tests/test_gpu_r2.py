@@ -317,6 +317,43 @@ def test_layout_and_launch_options_do_not_change_a_bit(m):
     assert np.isfinite(waves["dense"]).all() and np.abs(waves["dense"] - 1).max() > 1e-3   # not the vacuum wave
 
 
+def test_dense_specimen_stops_asking_for_empty_slices(oracle):
+    """`skip_empty` asks once per configuration which slices hold no atom (one D2H and one host wait on the lane).  After
+    eight configurations in a row without an empty slice the engine stops asking (and asks again every 64th): every slice
+    then takes the full sequence, which is what it took anyway.  The same configuration run before and after that point
+    gives the same bits, and a specimen WITH empty slices keeps being asked (its result stays that of the per-slice
+    decision, equal to the full sequence within rounding)."""
+    hp, at = S.case_tiny(m=256, m3=6, nz=2, frPh=24, nat=900, zfrac=0.5, seed=5)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0, lanes=1, split=0)
+    pl = eng.plan(hp, at)
+    first = pl.tap_wave(0, 3)
+    pl.begin_measurement(0)
+    for j in range(20):
+        pl.run_config(0, j, 1.0 / 20)
+    pl.sync()
+    assert pl.empty_queries() == 8          # the tap and seven configurations; the other thirteen were not asked
+    late = pl.tap_wave(0, 3)
+    assert np.array_equal(first.view(np.float32), late.view(np.float32))
+    assert relerr(late, oracle.wave(oracle.sub_sliced(hp)[0], at, 0, 3, prec="f64")) < 2e-5
+    pl.close(); eng.close()
+    # a specimen with vacuum above and below: every configuration is asked, the short cut keeps being taken
+    hp2, at2 = S.case_tiny(m=256, m3=12, nz=2, frPh=24, nat=300, zfrac=0.2, seed=6)
+    fdes_amd.consistent(hp2)
+    waves = []
+    for skip in (1, 0):
+        eng = fdes_amd.Engine(0, lanes=1, split=0, skip_empty=skip)
+        pl = eng.plan(hp2, at2)
+        pl.begin_measurement(0)
+        for j in range(12):
+            pl.run_config(0, j, 1.0 / 12)
+        pl.sync()
+        assert pl.empty_queries() == (12 if skip else 0)
+        waves.append(pl.tap_wave(0, 5))
+        pl.close(); eng.close()
+    assert relerr(waves[0], waves[1]) < 1e-6
+
+
 @pytest.mark.parametrize("kw", [dict(m=256, m3=6, nz=2, frPh=4, nat=150, tilt=True), dict(m=256, m3=4, nz=2, mode=2, nat=80),
                                 dict(m=1024, m3=5, nz=3, frPh=3, nat=300, beam_tilt=True, n3=2)])
 def test_fused_path_is_bit_reproducible(kw):
