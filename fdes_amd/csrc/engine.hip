@@ -46,12 +46,6 @@ struct fdes_ctx {
     float* share_GT = nullptr;
     int band_skip = 1;    // do not move / transform the rows and columns the 2/3 band limit zeroes anyway
     int skip_empty = 1;   // slices without atoms: t = 1, only the Fresnel step is applied (fused loop)
-    // skip_empty bookkeeping of the owner context: configurations in a row in which no slice was empty, configurations seen.
-    // A dense specimen (a crystal that fills the box) never has an empty slice: after kDenseAfter such configurations the
-    // per-configuration question (one D2H of the segment table and one host wait on the lane's stream) is only asked every
-    // kDenseRecheck-th configuration; meanwhile every slice takes the full sequence, which is always correct.
-    int dense_streak = 0;
-    int64_t cfg_seen = 0, empty_queries = 0;
     int lanes_active = 0; // > 0: run_config only deals to the first n lanes (bench: time a kernel without a co-running lane)
     int lanes = 0;        // configurations in flight at once (own stream + buffers each) in the fused slice loop; 0: by grid size
     int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
@@ -109,6 +103,14 @@ struct fdes_plan {
     std::vector<hipEvent_t> lane_ev;
     bool is_lane = false;
     fdes_ctx* parent_ctx = nullptr;    // lanes follow the runtime options (probe_stride) of the context that owns the plan
+    fdes_plan* top = nullptr;          // lanes: the plan they belong to
+    // skip_empty bookkeeping of a (top-level) plan: configurations in a row in which no slice was empty, configurations
+    // seen, questions asked.  A dense specimen (a crystal that fills the box) never has an empty slice: after kDenseAfter
+    // such configurations the per-configuration question (one D2H of the segment table and one host wait on the lane's
+    // stream) is only asked every kDenseRecheck-th configuration; meanwhile every slice takes the full sequence, which is
+    // always correct.
+    int dense_streak = 0;
+    int64_t cfg_seen = 0, empty_queries = 0;
     unsigned rr = 0;                    // round-robin lane selector
     bool lanes_dirty = false;           // lanes hold partial sums not yet folded into lane 0
     std::vector<int> seg_h;             // host copy of the (slice, species) segment table of the current configuration
@@ -262,20 +264,20 @@ int config_atoms(fdes_plan* pl, int k, int j)
         HIPCHK(c, hipMemcpyAsync(pl->xyzFP_d, pl->xyzK_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, c->stream));
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
     HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, pl->fused, c->stream));
-    fdes_ctx* oc = pl->parent_ctx ? pl->parent_ctx : pl->ctx;
+    fdes_plan* tp = pl->top ? pl->top : pl;
     constexpr int kDenseAfter = 8, kDenseRecheck = 64;
-    bool ask = pl->fused && oc->skip_empty;
-    if (ask && oc->dense_streak >= kDenseAfter && (oc->cfg_seen % kDenseRecheck) != 0) ask = false;
-    oc->cfg_seen++;
+    bool ask = pl->fused && owner_ctx(pl)->skip_empty;
+    if (ask && tp->dense_streak >= kDenseAfter && (tp->cfg_seen % kDenseRecheck) != 0) ask = false;
+    tp->cfg_seen++;
     if (ask) {
         // which slices hold atoms decides the launch sequence: one small D2H per configuration
         pl->seg_h.resize((size_t)pl->p.m3 * pl->nZ + 1);
         HIPCHK(c, hipMemcpyAsync(pl->seg_h.data(), pl->bins.seg, sizeof(int) * pl->seg_h.size(), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        oc->empty_queries++;
+        tp->empty_queries++;
         bool any_empty = false;
         for (int q = 0; q < pl->p.m3 && !any_empty; q++) any_empty = pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ];
-        oc->dense_streak = any_empty ? 0 : oc->dense_streak + 1;
+        tp->dense_streak = any_empty ? 0 : tp->dense_streak + 1;
     } else {
         pl->seg_h.clear();
     }
@@ -563,86 +565,82 @@ int incoming_wave(fdes_plan* pl, int k)
 int slice_loop(fdes_plan* pl, int nslices)
 {
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
-    if (pl->fused) {
-        fdes_ctx* c = pl->ctx;
-        const fdes_ctx* oc = owner_ctx(pl); // lanes follow the owner's runtime options
-        const bool timing_probe = (oc->probe_stride > 0);
-        // the two-stream loop is issued directly: captured, its cross-stream edges cost 5 % (12.2 k against 12.85 k)
-        if (!oc->opt_graph || timing_probe || nslices < 1 || pl->split) {
+    fdes_ctx* c = pl->ctx;
+    const fdes_ctx* oc = owner_ctx(pl); // lanes follow the owner's runtime options
+    // the launch sequence of one configuration: fused LDS passes, or rocFFT + point-wise kernels for the other grid sizes
+    auto issue = [&]() -> int {
+        if (pl->fused) {
             RC(fused_enter(pl));
             RC(split_fork(pl));
             for (int s = 0, adv = 1; s < nslices; s += adv) RC(fused_slice(pl, s, nslices, &adv));
             RC(split_join(pl));
             return fused_leave(pl, nslices > 0);
         }
-        // key: slice count, band option and the empty-slice pattern (FNV-1a over one bit per slice)
-        uint64_t key = 1469598103934665603ull;
-        auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
-        // the pattern itself (slice count, band option, one byte per slice) is kept beside its hash and compared on a
-        // hit: a colliding hash must not replay another pattern's launch sequence
-        std::vector<uint8_t> pattern;
-        pattern.reserve((size_t)pl->p.m3 + 8);
-        for (int b = 0; b < 4; b++) pattern.push_back((uint8_t)((unsigned)nslices >> (8 * b)));
-        pattern.push_back((uint8_t)oc->band_skip);
-        pattern.push_back((uint8_t)oc->walk);
-        pattern.push_back((uint8_t)(pl->split ? 1 : 0));
-        pattern.push_back(pl->seg_h.empty() ? 0 : 1);
-        if (!pl->seg_h.empty())
-            for (int q = 0; q < pl->p.m3; q++) pattern.push_back(pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ] ? 2 : 3);
-        for (uint8_t b : pattern) mix(b);
-        fdes_plan::LoopGraph* g = nullptr;
-        for (auto& e : pl->graphs) if (e.key == key && e.pattern == pattern) g = &e;
-        if (!g) {
-            std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
-            const int64_t skipped0 = pl->slices_skipped;
-            std::vector<std::pair<int, float2*>> pow_owned;
-            pl->capture_pow = &pow_owned;
-            pl->capturing = true;
-            hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
-            int rc = FDES_OK;
-            if (e == hipSuccess) {
-                rc = fused_enter(pl);
-                if (rc == FDES_OK) rc = split_fork(pl);
-                for (int s = 0, adv = 1; s < nslices && rc == FDES_OK; s += adv) rc = fused_slice(pl, s, nslices, &adv);
-                if (rc == FDES_OK) rc = split_join(pl);
-                if (rc == FDES_OK) rc = fused_leave(pl, true);
-            }
-            hipGraph_t graph = nullptr;
-            hipError_t e2 = (e == hipSuccess) ? hipStreamEndCapture(c->stream, &graph) : e;
-            pl->capturing = false;
-            pl->capture_pow = nullptr;
-            const int64_t skipped = pl->slices_skipped - skipped0;
-            pl->slices_skipped = skipped0;
-            hipGraphExec_t exec = nullptr;
-            hipError_t e3 = hipSuccess;
-            if (rc == FDES_OK && e2 == hipSuccess) e3 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            if (graph) (void)hipGraphDestroy(graph);
-            if (rc != FDES_OK || e2 != hipSuccess || e3 != hipSuccess) {
-                for (auto& e : pow_owned) (void)hipFree(e.second);
-                if (rc != FDES_OK) return rc;
-                HIPCHK(c, e2);
-                HIPCHK(c, e3);
-            }
-            if (pl->graphs.size() >= 8) { // drop the least recently used pattern
-                size_t lru = 0;
-                for (size_t i = 1; i < pl->graphs.size(); i++) if (pl->graphs[i].used < pl->graphs[lru].used) lru = i;
-                (void)hipStreamSynchronize(c->stream); // a replay of the evicted graph may still be reading its tables
-                (void)hipGraphExecDestroy(pl->graphs[lru].exec);
-                for (auto& e : pl->graphs[lru].pow) (void)hipFree(e.second);
-                pl->graphs.erase(pl->graphs.begin() + (long)lru);
-            }
-            pl->graphs.push_back({key, pattern, exec, skipped, 0, pow_owned});
-            g = &pl->graphs.back();
+        for (int s = 0; s < nslices; s++) {
+            if ((s & 1) == 0) RC(phase_grating_pair(pl, pl->xyzFP_d, g, s));
+            RC(forward_propagation(pl, s & 1));
         }
-        g->used = ++pl->graph_tick;
-        HIPCHK(c, hipGraphLaunch(g->exec, c->stream));
-        pl->slices_skipped += g->skipped;
         return FDES_OK;
+    };
+    const bool timing_probe = (oc->probe_stride > 0);
+    // the two-stream loop is issued directly: captured, its cross-stream edges cost 5 % (12.2 k against 12.85 k)
+    if (!oc->opt_graph || timing_probe || nslices < 1 || (pl->fused && pl->split)) return issue();
+    // key: slice count, band option and the empty-slice pattern (FNV-1a over one bit per slice)
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+    // the pattern itself (slice count, band option, one byte per slice) is kept beside its hash and compared on a
+    // hit: a colliding hash must not replay another pattern's launch sequence
+    std::vector<uint8_t> pattern;
+    pattern.reserve((size_t)pl->p.m3 + 8);
+    for (int b = 0; b < 4; b++) pattern.push_back((uint8_t)((unsigned)nslices >> (8 * b)));
+    pattern.push_back((uint8_t)oc->band_skip);
+    pattern.push_back((uint8_t)oc->walk);
+    pattern.push_back((uint8_t)(pl->split ? 1 : 0));
+    pattern.push_back(pl->seg_h.empty() ? 0 : 1);
+    if (!pl->seg_h.empty())
+        for (int q = 0; q < pl->p.m3; q++) pattern.push_back(pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ] ? 2 : 3);
+    for (uint8_t b : pattern) mix(b);
+    fdes_plan::LoopGraph* gr = nullptr;
+    for (auto& e : pl->graphs) if (e.key == key && e.pattern == pattern) gr = &e;
+    if (!gr) {
+        std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
+        const int64_t skipped0 = pl->slices_skipped;
+        std::vector<std::pair<int, float2*>> pow_owned;
+        pl->capture_pow = &pow_owned;
+        pl->capturing = true;
+        hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
+        int rc = FDES_OK;
+        if (e == hipSuccess) rc = issue();
+        hipGraph_t graph = nullptr;
+        hipError_t e2 = (e == hipSuccess) ? hipStreamEndCapture(c->stream, &graph) : e;
+        pl->capturing = false;
+        pl->capture_pow = nullptr;
+        const int64_t skipped = pl->slices_skipped - skipped0;
+        pl->slices_skipped = skipped0;
+        hipGraphExec_t exec = nullptr;
+        hipError_t e3 = hipSuccess;
+        if (rc == FDES_OK && e2 == hipSuccess) e3 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc != FDES_OK || e2 != hipSuccess || e3 != hipSuccess) {
+            for (auto& e : pow_owned) (void)hipFree(e.second);
+            if (rc != FDES_OK) return rc;
+            HIPCHK(c, e2);
+            HIPCHK(c, e3);
+        }
+        if (pl->graphs.size() >= 8) { // drop the least recently used pattern
+            size_t lru = 0;
+            for (size_t i = 1; i < pl->graphs.size(); i++) if (pl->graphs[i].used < pl->graphs[lru].used) lru = i;
+            (void)hipStreamSynchronize(c->stream); // a replay of the evicted graph may still be reading its tables
+            (void)hipGraphExecDestroy(pl->graphs[lru].exec);
+            for (auto& e : pl->graphs[lru].pow) (void)hipFree(e.second);
+            pl->graphs.erase(pl->graphs.begin() + (long)lru);
+        }
+        pl->graphs.push_back({key, pattern, exec, skipped, 0, pow_owned});
+        gr = &pl->graphs.back();
     }
-    for (int s = 0; s < nslices; s++) {
-        if ((s & 1) == 0) RC(phase_grating_pair(pl, pl->xyzFP_d, g, s));
-        RC(forward_propagation(pl, s & 1));
-    }
+    gr->used = ++pl->graph_tick;
+    HIPCHK(c, hipGraphLaunch(gr->exec, c->stream));
+    pl->slices_skipped += gr->skipped;
     return FDES_OK;
 }
 
@@ -1094,6 +1092,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             if (lrc != FDES_OK) { c->err = "lane plan: " + lc->err; fdes_plan_destroy(pl); return lrc; }
             lp->is_lane = true;
             lp->parent_ctx = c;
+            lp->top = pl;
             pl->lanes.push_back(lp);
             hipEvent_t ev;
             PLHIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1228,7 +1227,7 @@ int fdes_plan_get_images(fdes_plan* pl, float* image)
 int fdes_plan_fft_backend(const fdes_plan* pl) { return pl ? pl->fft->backend : FDES_EINVAL; }
 int fdes_plan_lanes(const fdes_plan* pl) { return pl ? (int)pl->lanes.size() + 1 : FDES_EINVAL; }
 int fdes_plan_num_slices(const fdes_plan* pl) { return pl ? pl->p.m3 : FDES_EINVAL; }
-int64_t fdes_plan_empty_queries(const fdes_plan* pl) { return pl ? owner_ctx(pl)->empty_queries : 0; }
+int64_t fdes_plan_empty_queries(const fdes_plan* pl) { return pl ? (pl->top ? pl->top : pl)->empty_queries : 0; }
 
 int64_t fdes_plan_slices_done(const fdes_plan* pl)
 {
