@@ -140,6 +140,70 @@ int main(int argc, char** argv)
         (void)read_with(fdes_read_qsc, T + "/ok.qsc", 0);
     }
     { std::string c2 = cfg; for (size_t i = 0; i < c2.size(); i += 31) c2[i] = 'Q'; spit(T + "/SrTiO3.cfg", c2); (void)read_with(fdes_read_qsc, T + "/ok.qsc", 0); }
+    // ---- seeded mutation fuzz: byte flips, deleted / duplicated / swapped lines, numbers replaced by extremes.  400 .cnf and
+    // 200 .qsc mutants, all reader modes; the only requirement is that nothing but a return code comes back.
+    {
+        unsigned long long st = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&](size_t n) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return n ? (size_t)(st % n) : (size_t)0; };
+        auto lines_of = [](const std::string& t) {
+            std::vector<std::string> L;
+            std::stringstream ss(t);
+            std::string l;
+            while (std::getline(ss, l)) L.push_back(l);
+            return L;
+        };
+        const char* extremes[] = {"-1", "0", "1e38", "-1e38", "1e-45", "nan", "inf", "2147483648", "-2147483649", "99999999999999999999", "", "0x10", "1,5", "1e", "--3", "+"};
+        auto mutate = [&](const std::string& src) {
+            std::vector<std::string> L = lines_of(src);
+            const int ops = 1 + (int)rnd(4);
+            for (int o = 0; o < ops && !L.empty(); o++) {
+                const size_t i = rnd(L.size());
+                switch (rnd(6)) {
+                case 0: L.erase(L.begin() + (long)i); break;
+                case 1: L.insert(L.begin() + (long)i, L[rnd(L.size())]); break;
+                case 2: std::swap(L[i], L[rnd(L.size())]); break;
+                case 3: { // replace the value after the colon (or the whole line) by an extreme
+                    const size_t c = L[i].find(':');
+                    L[i] = (c == std::string::npos ? std::string() : L[i].substr(0, c + 1) + " ") + extremes[rnd(sizeof(extremes) / sizeof(extremes[0]))];
+                    break;
+                }
+                case 4: if (!L[i].empty()) L[i][rnd(L[i].size())] = (char)rnd(256); break;
+                default: L[i] += " " + std::string(rnd(300), (char)('0' + rnd(10))); break;
+                }
+            }
+            std::string out;
+            for (const auto& l : L) out += l + "\n";
+            if (rnd(8) == 0) out.resize(rnd(out.size() + 1));
+            return out;
+        };
+        // a short .cnf (the header of the shipped one + its first 40 atoms) keeps 400 x 3 parses fast
+        std::string small;
+        {
+            std::vector<std::string> L = lines_of(good);
+            int atoms = 0;
+            for (const auto& l : L) {
+                const bool is_atom = l.rfind("atom:", 0) == 0;
+                if (is_atom && ++atoms > 40) continue;
+                small += l + "\n";
+            }
+        }
+        for (int m = 0; m < 400; m++) {
+            const std::string f = T + "/fuzz.cnf";
+            spit(f, mutate(small));
+            for (int flags : {0, FDES_CNF_BUG_COMPATIBLE, FDES_CNF_SKIP_ATOMS}) (void)read_with(fdes_read_cnf, f, flags);
+        }
+        spit(T + "/SrTiO3.cfg", cfg);
+        for (int m = 0; m < 200; m++) {
+            spit(T + "/fuzz.qsc", mutate(qsc));
+            (void)read_with(fdes_read_qsc, T + "/fuzz.qsc", 0);
+            if (m % 4 == 0) { // the cell file as well
+                spit(T + "/SrTiO3.cfg", mutate(cfg));
+                (void)read_with(fdes_read_qsc, T + "/ok.qsc", 0);
+                spit(T + "/SrTiO3.cfg", cfg);
+            }
+        }
+        std::printf("fuzz: 400 .cnf, 200 .qsc, 50 .cfg mutants parsed or refused\n");
+    }
     // ---- atoms from a flat array (the legacy export's path)
     {
         std::vector<float> arr = {79, 0, 0, 0, 6e-21f, 1.7f, 14, 1e-10f, 0, 0, 6e-21f, 0.4f};
