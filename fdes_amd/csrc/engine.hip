@@ -1032,7 +1032,9 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // split: the potential chain of the next slice pair runs beside the wave chain of this one, so the buffers that
         // one stream shares between its own consecutive passes stay aliased (A and C) and those that cross streams do
         // not (B, two E, F): 7 grids per lane instead of 4
-        pl->split = c->split > 0 || (c->split < 0 && plan_lanes(c, pl) == 1);
+        // (auto: one-lane plans from 2^20 pixels on; below that the single-stream hipGraph wins: 256^2 x 32 slices 35.5 k
+        // against 27.4 k slice-propagations/s, 512^2 x 32 27.6 k against 23.4 k, 1024^2 x 32 17.6 k against 19.8 k)
+        pl->split = c->split > 0 || (c->split < 0 && plan_lanes(c, pl) == 1 && pl->m12 >= ((size_t)1 << 20));
         PLCHK(dmalloc(c, &pl->C, pl->gsz));
         if (pl->split) PLCHK(dmalloc(c, &pl->F, pl->gsz)); else pl->F = pl->C;
         if (pl->nZ == 1) pl->A = pl->C;

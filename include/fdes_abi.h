@@ -244,7 +244,7 @@ int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_
  *                dealt round-robin to lanes, partial intensity sums are folded in end_measurement
  *   "pass_threads"  0 auto, 256 or 512 threads per LDS-pass workgroup
  *   "split"      -1 (default): a plan with one lane (single-image jobs; a plan never has more lanes than the job has
- *                configurations) runs the potential / transmission passes of its slice loop on a second stream, one
+ *                configurations) and at least 2^20 pixels runs the potential / transmission passes of its slice loop on a second stream, one
  *                slice pair ahead of the wave's passes; 0 never, 1 always
  *   "pitch_pad"  -1 (default: 32 for 2048-point rows, 64 from 4096 on) elements of padding per row of the slice loop's grids
  *   "walk"       1 (default) .. 8: launch every pass in that many parts                                  */
