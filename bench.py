@@ -48,13 +48,25 @@ def main():
                          "slice runs the full potential/transmission/propagation sequence like the reference")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as `python bench.py --gpus N` without a launcher: this process becomes the launcher (it has not touched
+        # the GPU: no torch, no HIP call) and starts one fresh child per GPU, as torch.distributed.run would
+        sys.exit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FDES_BENCH_DRYRUN"):
+        # launcher rehearsal without a GPU (tests/test_host_cpu.py): every rank reports what it WOULD run
+        print(json.dumps({"dryrun": True, "rank": rank, "world": world, "local_rank": local, "gpus_flag": args.gpus,
+                          "warmup_j": [1000 + deal(rank, world, w) for w in range(args.warmup)],
+                          "timed_j": [deal(rank, world, s) for s in range(args.steps)]}), flush=True)
+        return
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     # FDES_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer GPUs than ranks (ranks share devices, reductions go
     # through host memory); the default is RCCL ("nccl"), one rank per GPU.
     backend = os.environ.get("FDES_BENCH_BACKEND", "nccl")
@@ -97,14 +109,14 @@ def main():
         for lane in range(plan.lanes()):
             plan.run_config(0, 3000 + lane, 0.0)
         for w in range(args.warmup):
-            plan.run_config(0, 1000 + rank + world * w, 0.0)  # untimed, weight 0: does not touch the sum
+            plan.run_config(0, 1000 + deal(rank, world, w), 0.0)  # untimed, weight 0: does not touch the sum
         plan.sync()
         plan.slice_loop_ms()
         plan.probe_ms()
         barrier()
         t0 = time.perf_counter()
         for s in range(args.steps):
-            plan.run_config(0, rank + world * s, weight)
+            plan.run_config(0, deal(rank, world, s), weight)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -127,9 +139,9 @@ def main():
         plan.slice_loop_ms()
         # after the timed region: one all-reduce of the partial intensity sums, then the detector chain
         if world > 1:
-            ptr, nbytes = plan.intensity_ptr()
-            buf = torch.empty(nbytes // 4, device="cuda", dtype=torch.float32)
-            plan.copy_intensity(buf.data_ptr(), 0)
+            # the intensity sum is real: the collective moves its float view (16 MiB at 2048^2), not the float2 grid
+            buf = torch.empty(m * m, device="cuda", dtype=torch.float32)
+            plan.copy_intensity_real(buf.data_ptr(), 0)
             if backend == "nccl":
                 dist.all_reduce(buf)
             else:
@@ -137,7 +149,7 @@ def main():
                 dist.all_reduce(hb)
                 buf.copy_(hb)
             torch.cuda.synchronize()
-            plan.copy_intensity(buf.data_ptr(), 1)
+            plan.copy_intensity_real(buf.data_ptr(), 1)
         plan.end_measurement(0)
         img = plan.get_images()
         return dt, plan, eng, loop_ms, loop_slices, fft_ms, fft_n, bool(np.isfinite(img).all()), img
@@ -229,6 +241,34 @@ def main():
 
 
 ENGINE_BYTES_PER_PX_SLICE = 60.67
+
+
+def deal(rank, world, step):
+    """Frozen-phonon configuration j that `rank` of `world` runs in its step `step`: rank + world * step, so that the
+    ranks' steps together cover j = 0 .. world * steps - 1 exactly once (tests/test_host_cpu.py)."""
+    return rank + world * step
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher: start N child processes of this script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, one GPU each) and return the worst exit code.  The
+    parent never initialises the GPU; rank 0's JSON line reaches stdout through the inherited descriptor."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
 
 
 def _blob_hash(path):

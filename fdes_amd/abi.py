@@ -131,7 +131,7 @@ class HostAtoms:
 # fdes_progress_fn: void (*)(void* user, int64_t done, int64_t total)
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
-# (name, restype, argtypes) of every symbol include/fdes_abi.h declares
+# (name, restype, argtypes) of every symbol include/fdes_abi.h and include/fdes_abi_test.h declare
 _P = C.POINTER
 _vp = C.c_void_p
 PROTOTYPES = [
@@ -169,6 +169,7 @@ PROTOTYPES = [
     ("fdes_plan_end_measurement", C.c_int, [_vp, C.c_int]),
     ("fdes_plan_intensity_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
     ("fdes_plan_copy_intensity", C.c_int, [_vp, _vp, C.c_int]),
+    ("fdes_plan_copy_intensity_real", C.c_int, [_vp, _vp, C.c_int]),
     ("fdes_plan_images_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
     ("fdes_plan_get_images", C.c_int, [_vp, _P(C.c_float)]),
     ("fdes_plan_sync", C.c_int, [_vp]),

@@ -260,6 +260,10 @@ class Plan:
     def copy_intensity(self, dev_ptr, to_plan):
         self._c(self.lib.fdes_plan_copy_intensity(self.h, C.c_void_p(dev_ptr), int(to_plan)))
 
+    def copy_intensity_real(self, dev_ptr, to_plan):
+        """float[m1*m2] view of the running intensity sum (its imaginary part is identically zero)."""
+        self._c(self.lib.fdes_plan_copy_intensity_real(self.h, C.c_void_p(dev_ptr), int(to_plan)))
+
     def images_ptr(self):
         p, n = C.c_void_p(), C.c_size_t()
         self._c(self.lib.fdes_plan_images_ptr(self.h, C.byref(p), C.byref(n)))

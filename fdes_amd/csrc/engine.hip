@@ -50,9 +50,11 @@ struct fdes_ctx {
     int lanes = 0;        // configurations in flight at once (own stream + buffers each) in the fused slice loop; 0: by grid size
     int pass_threads = 0; // 0 auto: 256-thread pass workgroups (two per CU) when lanes > 1 and the grid allows, else 512
     int split = -1;       // potential / transmission passes (P1'..P4) on a stream of their own, one slice pair ahead of the
-                          // wave's passes (P5, P6): concurrency inside ONE configuration; -1 auto, 0 off, 1 on
-    int walk = 1;         // row groups per pass workgroup (2: a pass takes half of the workgroup slots, two lanes' passes share every CU)
-    int pitch_pad = -1;   // elements added to every row of the fused loop's grids; -1 auto: 64 from 2048-point rows on
+                          // wave's passes (P5, P6): concurrency inside ONE configuration; -1 auto, 0 off, 1 on (issued
+                          // directly, never captured into a graph)
+    int walk = 1;         // every pass is launched in this many parts (2: a part takes half of the workgroup slots, two lanes' passes share every CU)
+    int pitch_pad = -1;   // elements added to every row of the fused loop's grids; -1 auto: 32 for 2048-point rows, 64 from 4096 on
+    int peer_copy = 1;    // 0: fdes_plan_accumulate_from stages partial sums through host memory instead of a peer copy (the fallback path, forced)
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
     // plans are expensive to create: one per grid size AND requested back-end (option "fft" may change between plans)
     std::map<std::tuple<int, int, int>, Fft2D*> fft_cache;
@@ -142,11 +144,16 @@ struct fdes_plan {
     bool want_ew = false;
     // split slice loop: the potential chain runs on `vs`, the wave chain on the context's stream
     bool split = false, tap_mode = false;
+    // the incoming wave of the current configuration is band-limited in kx (set by incoming_wave): every case except a
+    // CBED probe with a beam tilt, whose phase ramp comes after the band limit (src/multisliceSimulation.cu:583-590)
+    bool wave_bl = true;
     hipStream_t vs = nullptr;
     float2* Eb[2] = {nullptr, nullptr};  // band-limited transmission spectra of the pair's two slices (split: two buffers)
     hipEvent_t evE[2] = {nullptr, nullptr}, evP5[2] = {nullptr, nullptr}, evFork = nullptr, evJoin = nullptr;
     bool p5_seen[2] = {false, false};
     float2* peer_stage = nullptr;   // landing buffer for another GPU's partial sum (fdes_plan_accumulate_from)
+    bool peer_host_only = false;    // the peer copy was refused once: partial sums are staged through host memory (option "peer_copy" 0 forces it)
+    std::vector<float2> peer_host;
     hipEvent_t peer_ev = nullptr;
     // timing
     std::vector<EvPair> evs;
@@ -431,6 +438,8 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
         PassArgs a5 = pass_x(pl);
         a5.in0 = pl->PSIH; a5.out = pl->F;
         a5.scale = (float)m1; // P5 hands m1 * FFT_x(t psi) to P6 (unnormalised x round trip); exact power of two
+        // (an incoming wave that is not band-limited in kx needs no special case here: the dead kx rows this copy drops are
+        // zeroed by the masked propagator whatever they held)
         a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
         HIPCHK(c, lds_pass(m1, XF_NONE, MID_SCALE, XF_NONE, true, a5, c->stream));
         int run = 1;
@@ -467,7 +476,11 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
     }
     PassArgs a5 = pass_x(pl);
     a5.in0 = pl->Eb[ei]; a5.in1 = pl->PSIH; a5.out = pl->F;
-    a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
+    // Dead kx columns: E's are never written by P4 (they may hold the pair potential's stale values: B aliases E), so
+    // they are always skipped; psi-hat's are exact zeros after any masked propagator, but the FIRST product of a
+    // configuration sees the incoming wave, which the reference multiplies by t in full (src/multisliceSimulation.cu:546)
+    // and which is not band-limited in kx when a tilted CBED probe leaves the band (:583-590) - then all of it is read.
+    a5.band = band; a5.skip_dead_loads = bs ? ((s == 0 && !pl->wave_bl) ? 1 : 3) : 0; a5.skip_dead_stores = bs;
     // roofline probe: P5 is the longest kernel of the loop; every probe_stride-th launch is bracketed by events
     const int pstride = owner_ctx(pl)->probe_stride;
     const bool probe = !pl->capturing && pstride > 0 && (pl->fft_calls++ % (uint64_t)pstride) == 0;
@@ -545,6 +558,7 @@ int incoming_wave(fdes_plan* pl, int k)
     fdes_ctx* c = pl->ctx;
     const fdes_params& p = pl->p;
     HIPCHK(c, k_fill(pl->PSI, pl->m12, 1.f, 0.f, c->stream));
+    pl->wave_bl = !(p.mode == 2 && p.doBeamTilt);
     if (p.mode == 2) {
         HIPCHK(c, k_lens(pl->PSI, pl->kp, p.defoci[k], c->stream));
         HIPCHK(c, fft_exec(pl,pl->PSI, true, c->stream));
@@ -596,6 +610,7 @@ int slice_loop(fdes_plan* pl, int nslices)
     pattern.push_back((uint8_t)oc->band_skip);
     pattern.push_back((uint8_t)oc->walk);
     pattern.push_back((uint8_t)(pl->split ? 1 : 0));
+    pattern.push_back((uint8_t)(pl->wave_bl ? 1 : 0));
     pattern.push_back(pl->seg_h.empty() ? 0 : 1);
     if (!pl->seg_h.empty())
         for (int q = 0; q < pl->p.m3; q++) pattern.push_back(pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ] ? 2 : 3);
@@ -859,6 +874,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "skip_empty")) { c->skip_empty = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "lanes")) { if (value < 0 || value > 4) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "peer_copy")) { c->peer_copy = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "probe_stride")) { c->probe_stride = (int)value; return FDES_OK; }
     return FDES_EINVAL;
 }
@@ -1198,6 +1214,19 @@ int fdes_plan_copy_intensity(fdes_plan* pl, void* dev_buf, int to_plan)
     return FDES_OK;
 }
 
+int fdes_plan_copy_intensity_real(fdes_plan* pl, void* dev_buf, int to_plan)
+{
+    if (!pl || !dev_buf) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    RC(fold_lanes(pl));
+    // dev_buf must be DEVICE memory here (a kernel reads / writes it); I.y is identically zero (k_intensity_axpy)
+    if (to_plan) HIPCHK(c, k_real_unpack(pl->I, (const float*)dev_buf, pl->m12, c->stream));
+    else HIPCHK(c, k_real_pack((float*)dev_buf, pl->I, pl->m12, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDES_OK;
+}
+
 int fdes_plan_images_ptr(fdes_plan* pl, void** dev_ptr, size_t* bytes)
 {
     if (!pl || !dev_ptr) return FDES_EINVAL;
@@ -1327,7 +1356,9 @@ int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src)
     HIPCHK(dc, hipSetDevice(dc->device));
     RC(fold_lanes(dst));
     HIPCHK(dc, hipStreamWaitEvent(dc->stream, src->peer_ev, 0));
-    const bool same = dc->device == sc->device;
+    const bool forced_host = owner_ctx(dst)->peer_copy == 0; // test option: take the host-staged path even on one device
+    if (forced_host) dst->peer_host_only = true;
+    const bool same = dc->device == sc->device && !forced_host;
     if (!same && !dst->peer_stage) {
         std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc vs a capture in another thread
         RC(dmalloc(dc, &dst->peer_stage, dst->m12));
@@ -1337,7 +1368,24 @@ int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src)
         float2* acc = q ? dst->EW : dst->I;
         const float2* part = q ? src->EW : src->I;
         if (!same) {
-            HIPCHK(dc, hipMemcpyPeerAsync(dst->peer_stage, dc->device, part, sc->device, sizeof(float2) * dst->m12, dc->stream));
+            // xGMI peer copy; when the runtime refuses it (no peer access between the two devices, or the copy itself
+            // fails) the partial sum is staged through host memory instead - slower, never wrong
+            int can = 0;
+            hipError_t pe = hipDeviceCanAccessPeer(&can, dc->device, sc->device);
+            if (pe == hipSuccess && can && !dst->peer_host_only)
+                pe = hipMemcpyPeerAsync(dst->peer_stage, dc->device, part, sc->device, sizeof(float2) * dst->m12, dc->stream);
+            else if (pe == hipSuccess) pe = hipErrorPeerAccessUnsupported;
+            if (pe != hipSuccess) {
+                (void)hipGetLastError();
+                dst->peer_host_only = true;
+                dst->peer_host.resize(dst->m12);
+                HIPCHK(sc, hipSetDevice(sc->device));
+                HIPCHK(sc, hipMemcpyAsync(dst->peer_host.data(), part, sizeof(float2) * dst->m12, hipMemcpyDeviceToHost, sc->stream));
+                HIPCHK(sc, hipStreamSynchronize(sc->stream));
+                HIPCHK(dc, hipSetDevice(dc->device));
+                HIPCHK(dc, hipMemcpyAsync(dst->peer_stage, dst->peer_host.data(), sizeof(float2) * dst->m12, hipMemcpyHostToDevice, dc->stream));
+                HIPCHK(dc, hipStreamSynchronize(dc->stream)); // peer_host is reused by the next sum
+            }
             part = dst->peer_stage;
         }
         HIPCHK(dc, k_axpy(acc, part, dst->m12, 1.f, dc->stream));
@@ -1540,7 +1588,7 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
         if (c->bench_band) { // micro-benchmark of the band-limit bookkeeping: bit 0 live rows only, bit 1 dead loads, bit 2 dead stores
             A.band = n * n;
             A.live_rows_only = (c->bench_band & 1) ? 1 : 0;
-            A.skip_dead_loads = (c->bench_band & 2) ? 1 : 0;
+            A.skip_dead_loads = (c->bench_band & 2) ? 3 : 0;
             A.skip_dead_stores = (c->bench_band & 4) ? 1 : 0;
         }
         args.push_back(A);

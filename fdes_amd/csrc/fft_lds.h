@@ -61,7 +61,8 @@ struct PassArgs {
     int band = 0;
     int band_L = 0;              // largest live |i| (filled in by lds_pass)
     int live_rows_only = 0;      // the ROWS of this pass are frequencies: only row groups with a live row are launched
-    int skip_dead_loads = 0;     // the COLUMNS of the input are frequencies masked upstream: dead ones are not loaded (= 0)
+    int skip_dead_loads = 0;     // the COLUMNS of an input are frequencies masked upstream: dead ones are not loaded (= 0);
+                                 // bit 0: in0, bit 1: in1 (MID_MULPSI's second operand)
     int skip_dead_stores = 0;    // transposed store: output rows (= our columns) that the next pass never reads are not written
     // MID_ATOMS
     const void* recs = nullptr;  // AtomRec[] sorted by (slice, species, row)

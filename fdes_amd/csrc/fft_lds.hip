@@ -11,9 +11,11 @@
 //            through registers (FFT -> point-wise -> inverse FFT without touching LDS in between).
 // LDS rows are padded by one element per 16 (index i -> i + i/16): the stride-16 writes of stage 0
 // become stride 17 (conflict-free for ds_write_b64's 16-lane groups), reads stay contiguous.
-// A workgroup is 512 threads and R = 16384/N rows (8 rows at N = 2048), every thread carrying two
-// rows (shared twiddles, twice the work per barrier); LDS = 136 KiB -> one workgroup per CU,
-// 2 waves per SIMD with a 256-VGPR budget (the 1024-thread form spills at 128 VGPRs).  The transposed store stages the R x N tile through the
+// Workgroup geometries (template parameter WG, struct WGeo below): 256 threads x 2 rows per thread = 8192/N rows per
+// workgroup (4 rows at N = 2048, 68 KiB of LDS: TWO workgroups per CU; the default above 1024 points), 512 threads x 2
+// rows per thread for 4096-point rows (4 rows, 136 KiB, one workgroup per CU: 256 threads would cut the transposed-store
+// segments to 16 bytes), and N/4 threads x ONE row per thread (four rows per workgroup) for grids up to 1024^2, where a
+// pass lasts as long as its slowest workgroup.  The transposed store stages the R x N tile through the
 // same LDS (swizzled so both the row-wise write and the column-wise read are conflict-free) and
 // writes R contiguous elements per output row; blockIdx is remapped so that workgroups sharing an
 // XCD (blockIdx % 8 equal) own consecutive row groups and their partial 128-byte lines merge in
@@ -743,7 +745,7 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
             }
             __syncthreads(); // the staging area becomes the exchange buffer
         } else {
-        load_rows<N, WG>(a, in0, rbase, t, A.skip_dead_loads != 0);
+        load_rows<N, WG>(a, in0, rbase, t, (A.skip_dead_loads & 1) != 0);
         }
         STAMP(1, false);
         if constexpr (MID == MID_ZSRC) {
@@ -775,7 +777,7 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
                 for (int l = 0; l < 16; l++) gvv[h][l] = gtab[rbase[h] + t + T * l];
         }
         // second operand of the product: requested with the first so that its HBM round trip overlaps the first transform
-        if constexpr (MID == MID_MULPSI && FDES_P5_PREFETCH) load_rows<N, WG>(b, in1, rbase, t, A.skip_dead_loads != 0);
+        if constexpr (MID == MID_MULPSI && FDES_P5_PREFETCH) load_rows<N, WG>(b, in1, rbase, t, (A.skip_dead_loads & 2) != 0);
         STAMP(2, true);  // first operand (and tables) landed
         xform<N, WG, PRE, false, TWR>(a, lds, r, t, tw, gs);
         STAMP(3, false); // first transform done
@@ -862,7 +864,7 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
                 }
             }
         } else if constexpr (MID == MID_MULPSI) {
-            if constexpr (!FDES_P5_PREFETCH) load_rows<N, WG>(b, in1, rbase, t, A.skip_dead_loads != 0);
+            if constexpr (!FDES_P5_PREFETCH) load_rows<N, WG>(b, in1, rbase, t, (A.skip_dead_loads & 2) != 0);
             STAMP(4, true);  // second operand landed
             xform<N, WG, PRE, true, TWR>(b, lds, r, t, tw, gs);
             STAMP(5, false); // second transform done

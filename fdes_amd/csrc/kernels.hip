@@ -62,6 +62,9 @@ __global__ void kk_axpy(float2* __restrict__ y, const float2* __restrict__ x, si
     GS_LOOP(i, n) { float2 v = y[i]; const float2 u = x[i]; v.x += a * u.x; v.y += a * u.y; y[i] = v; }
 }
 
+__global__ void kk_real_pack(float* __restrict__ d, const float2* __restrict__ s, size_t n) { GS_LOOP(i, n) d[i] = s[i].x; }
+__global__ void kk_real_unpack(float2* __restrict__ d, const float* __restrict__ s, size_t n) { GS_LOOP(i, n) d[i] = make_float2(s[i], 0.f); }
+
 // ---- projectedPotential_d (src/projectedPotential.cu:30-73) * divideBySinc (src/crystalMaker.cu:
 // 136-158) * multiplyWithProjectedPotential_d (:160-172) + cublasCaxpy (:532), in Fourier space.
 // The reference materialises f_e(q) per slice and species and sums the species in real space after
@@ -514,6 +517,8 @@ hipError_t k_fill(float2* f, size_t n, float re, float im, hipStream_t st) { LAU
 hipError_t k_fill_noise(float* f, size_t n, unsigned seed, hipStream_t st) { LAUNCH(kk_fill_noise, n, st, f, n, seed); }
 hipError_t k_scale(float2* f, size_t n, float a, hipStream_t st) { LAUNCH(kk_scale, n, st, f, n, a); }
 hipError_t k_axpy(float2* y, const float2* x, size_t n, float a, hipStream_t st) { LAUNCH(kk_axpy, n, st, y, x, n, a); }
+hipError_t k_real_pack(float* d, const float2* s, size_t n, hipStream_t st) { LAUNCH(kk_real_pack, n, st, d, s, n); }
+hipError_t k_real_unpack(float2* d, const float* s, size_t n, hipStream_t st) { LAUNCH(kk_real_unpack, n, st, d, s, n); }
 hipError_t k_filter_accum(float2* Vh, float2* Dh, const KP& p, const Kirk& kz, int first, hipStream_t st)
 {
     LAUNCH(kk_filter_accum, (size_t)p.m1 * p.m2, st, Vh, Dh, p, kz, first);

@@ -167,6 +167,9 @@ int fdes_plan_intensity_ptr(fdes_plan* plan, void** dev_ptr, size_t* bytes);
  * fdes_plan_intensity_ptr reports; stream-ordered with the plan's work, synchronises before return.
  * Lets a host runtime (torch.distributed / RCCL) reduce I without aliasing library memory. */
 int fdes_plan_copy_intensity(fdes_plan* plan, void* dev_buf, int to_plan);
+/* The same with the real part only: dev_buf is float[m1*m2] (I.y is identically zero, so a collective over this
+ * view moves half the bytes: 16 MiB instead of 32 MiB at 2048^2).  to_plan = 1 writes I = (buf, 0). */
+int fdes_plan_copy_intensity_real(fdes_plan* plan, void* dev_buf, int to_plan);
 /* dst.I += src.I (and dst's exit-wave sum += src's when both plans want it), device to device: the reduction of
  * src/crystalMaker.cu:347-365 for a measurement whose configurations ran on two plans.  Plans on different GPUs of
  * the process: one peer copy into a landing buffer on dst's GPU + one axpy kernel.  Synchronises dst. */
@@ -191,55 +194,18 @@ int fdes_plan_lanes(const fdes_plan* plan);
 /* Number of (sub-)slices m3 after sub-slicing; slice-propagations done so far. */
 int fdes_plan_num_slices(const fdes_plan* plan);
 int64_t fdes_plan_slices_done(const fdes_plan* plan);
-/* How many configurations have been asked which of their slices are empty (option "skip_empty": one D2H and one host
- * wait each); a specimen without empty slices stops being asked after eight configurations in a row (diagnostic). */
-int64_t fdes_plan_empty_queries(const fdes_plan* plan);
 /* Mean device time [ms] of the slice loops between the HIP events recorded by
  * run_config since the last call (measurement). Synchronises. */
 int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
 
-/* Sum of the HIP-event durations [ms] of the probed launches of the dominant kernel (option
- * "probe_stride" = n > 0 brackets every n-th 2-D FFT with events on the plan's stream) since the
- * last call, and how many were probed.  Synchronises. */
-int fdes_plan_probe_ms(fdes_plan* plan, double* total_ms, int64_t* launches);
-
-/* ---- stage taps for parity tests (device results copied to HOST buffers) ---- */
-/* Atom coordinates used by configuration (k, j): tilt offset, tilt k, jitter. float[3*nAt]. */
-int fdes_plan_tap_coords(fdes_plan* plan, int k, int j, float* xyz);
-/* phaseGrating (src/crystalMaker.cu:507-536) of sub-slice s for configuration (k, j):
- * V as float[2*m1*m2] interleaved (.x = sigma*v_z, .y = imPot part). */
-int fdes_plan_tap_potential(fdes_plan* plan, int k, int j, int s, float* V);
-/* Wave after `nslices` slices of configuration (k, j) (nslices = m3 -> exit wave), before
- * any exit-wave post-processing. float[2*m1*m2]. */
-int fdes_plan_tap_wave(fdes_plan* plan, int k, int j, int nslices, float* psi);
-/* Band-limited Fresnel propagator as the slice loop applies it
- * (src/multisliceSimulation.cu:594-603). float[2*m1*m2]. */
-int fdes_plan_tap_propagator(fdes_plan* plan, float* P);
-/* One propagation unit on caller-provided DEVICE buffers (micro-benchmark and parity):
- * psi <- F^-1[ P * F[ t * psi ] ], batch wave functions of m2 x m1 float2 each;
- * t is shared (batch stride 0) or per-wave.  (src/multisliceSimulation.cu:546-548) */
-int fdes_plan_propagate_dev(fdes_plan* plan, void* psi_dev, const void* t_dev, int batch, int t_per_wave);
-
-/* Unnormalised 2-D C2C FFT of a HOST grid (float[2*m1*m2], idx = i2*m1 + i1) through the engine's FFT
- * back-end (cufftExecC2C stand-in; test hook).  backend: 0 auto, 1 rocFFT, 2 LDS kernels.
- * Returns the back-end used (1 or 2) or a negative error. */
-int fdes_fft2d_host(fdes_ctx* ctx, float* data, int m1, int m2, int inverse, int backend);
-
-/* Micro-benchmark of one LDS row pass on zero-filled n x n scratch grids: mean launch time [us].
- * pre/post: 0 none, 1 forward, 2 inverse row FFT; mid: point-wise op id (fft_lds.h); store_t: transposed store;
- * streams: launches are issued round-robin on this many HIP streams (own grids each), host-timed. */
-int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_t, int iters, int streams, double* us);
-
-/* Engine options (before fdes_plan_create).  Unknown keys -> FDES_EINVAL.
+/* Engine options (before fdes_plan_create).  Unknown keys -> FDES_EINVAL.  (Test / bench-only keys: fdes_abi_test.h.)
  *   "fft"        0 = auto, 1 = rocFFT, 2 = hand-written LDS FFT kernels (power-of-two grids)
  *   "graph"      1 = replay the slice loop from a hipGraph
  *   "seed"       frozen-phonon seed (reference: 1, src/crystalMaker.cu:292)
- *   "probe_stride"  see fdes_plan_probe_ms
  *   "band_skip"  1 (default): rows / columns that the radial 2/3 band limit zeroes whatever the other index is are
  *                neither transformed nor moved in the fused loop (exact: they hold zeros); 0: move everything
  *   "skip_empty" 1 (default): a slice that holds no atom has t = 1 exactly, so only its Fresnel step is run
  *                (2 passes instead of 5-6); 0: every slice goes through the full sequence like the reference
- *   "lanes_active"  n > 0: run_config deals only to the first n lanes from now on (0: all)
  *   "lanes"      1..4 configurations in flight at once in the fused slice loop (default 2): run_config calls are
  *                dealt round-robin to lanes, partial intensity sums are folded in end_measurement
  *   "pass_threads"  0 auto, 256 or 512 threads per LDS-pass workgroup
@@ -247,7 +213,9 @@ int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_
  *                configurations) and at least 2^20 pixels runs the potential / transmission passes of its slice loop on a second stream, one
  *                slice pair ahead of the wave's passes; 0 never, 1 always
  *   "pitch_pad"  -1 (default: 32 for 2048-point rows, 64 from 4096 on) elements of padding per row of the slice loop's grids
- *   "walk"       1 (default) .. 8: launch every pass in that many parts                                  */
+ *   "walk"       1 (default) .. 8: launch every pass in that many parts
+ *   "peer_copy"  1 (default): fdes_plan_accumulate_from moves a partial sum between GPUs by a peer copy and falls back
+ *                to host staging when the runtime refuses it; 0: always stage through host memory                 */
 int fdes_set_option(fdes_ctx* ctx, const char* key, int64_t value);
 
 /* Progress report.  The reference prints a percentage to stderr from inside its slice loop (progressCounter,

@@ -16,10 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "fdes_abi.h")).read()
+    import glob
+    hdrs = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+    assert [os.path.basename(h) for h in hdrs] == ["fdes_abi.h", "fdes_abi_test.h"]
+    hdr = "".join(open(h).read() for h in hdrs)
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(fdes_[a-z0-9_]+|FDES)\s*\(", hdr))
     declared.discard("fdes_abi_h_")
+    declared.discard("fdes_abi_test_h_")
     lib = fdes_amd.load_library()
     bound = {n for n, _, _ in abi.PROTOTYPES}
     assert declared == bound, (declared ^ bound)
@@ -539,3 +543,33 @@ def test_host_parsers_under_address_sanitizer(tmp_path):
     print(r.stdout[-1500:], r.stderr[-3000:])
     assert r.returncode == 0 and "all ok" in r.stdout
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_bench_deals_every_configuration_once_and_starts_its_own_ranks():
+    """bench.py: rank r runs configuration j = r + world * s in step s (src/crystalMaker.cu:324-367: the (k, j) loops are
+    independent), so the ranks' timed steps cover j = 0 .. world * steps - 1 exactly once; and `python bench.py --gpus N`
+    with no launcher starts N ranks itself (FDES_BENCH_DRYRUN: each rank prints what it would run and exits before any
+    GPU call)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (1, 2, 3, 8):
+        for steps in (1, 4, 7):
+            js = sorted(bench.deal(r, world, s) for r in range(world) for s in range(steps))
+            assert js == list(range(world * steps))
+    env = dict(os.environ, FDES_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "5", "--warmup", "2"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert sorted(l["rank"] for l in lines) == [0, 1, 2]
+    assert all(l["world"] == 3 and l["gpus_flag"] == 3 and l["local_rank"] == l["rank"] for l in lines)
+    assert sorted(j for l in lines for j in l["timed_j"]) == list(range(15))
+    # under a launcher (WORLD_SIZE set) the same script is one rank and starts nothing
+    env.update(WORLD_SIZE="2", RANK="1", LOCAL_RANK="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["rank"] == 1 and lines[0]["timed_j"] == [1, 3]
