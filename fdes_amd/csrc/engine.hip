@@ -52,6 +52,7 @@ struct fdes_ctx {
     int split = -1;       // potential / transmission passes (P1'..P4) on a stream of their own, one slice pair ahead of the
                           // wave's passes (P5, P6): concurrency inside ONE configuration; -1 auto, 0 off, 1 on (issued
                           // directly, never captured into a graph)
+    int stagger = 0;      // one-wave-per-row passes: start delay between the waves of a CU, in units of 64 cycles (0: none)
     int walk = 1;         // every pass is launched in this many parts (2: a part takes half of the workgroup slots, two lanes' passes share every CU)
     int pitch_pad = -1;   // elements added to every row of the fused loop's grids; -1 auto: 32 for 2048-point rows, 64 from 4096 on
     int peer_copy = 1;    // 0: fdes_plan_accumulate_from stages partial sums through host memory instead of a peer copy (the fallback path, forced)
@@ -356,8 +357,8 @@ int forward_propagation(fdes_plan* pl, int comp = -1)
 //   P6  F[kx][y]       -FFT_y, * P, IFFT_y->             PSIH[y][kx]
 // pass over the rows of an "N" grid ([y][kx], row length m1) with a transposed store into a "T" grid, and the reverse;
 // callers whose input or output is a dense natural grid (PSI, T, user buffers) override the pitch with 0
-PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; a.wg = pl->wg; a.pitch_in = pl->pitchN; a.pitch_out = pl->pitchT; a.walk = owner_ctx(pl)->walk; return a; }
-PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; a.wg = pl->wg; a.pitch_in = pl->pitchT; a.pitch_out = pl->pitchN; a.walk = owner_ctx(pl)->walk; return a; }
+PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; a.wg = pl->wg; a.pitch_in = pl->pitchN; a.pitch_out = pl->pitchT; a.walk = owner_ctx(pl)->walk; a.stagger = owner_ctx(pl)->stagger; return a; }
+PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.nrows = pl->p.m1; a.wg = pl->wg; a.pitch_in = pl->pitchT; a.pitch_out = pl->pitchN; a.walk = owner_ctx(pl)->walk; a.stagger = owner_ctx(pl)->stagger; return a; }
 
 // stream of the potential / transmission passes
 hipStream_t vstream(fdes_plan* pl) { return (pl->split && !pl->tap_mode) ? pl->vs : pl->ctx->stream; }
@@ -609,6 +610,8 @@ int slice_loop(fdes_plan* pl, int nslices)
     for (int b = 0; b < 4; b++) pattern.push_back((uint8_t)((unsigned)nslices >> (8 * b)));
     pattern.push_back((uint8_t)oc->band_skip);
     pattern.push_back((uint8_t)oc->walk);
+    pattern.push_back((uint8_t)(oc->stagger & 255));
+    pattern.push_back((uint8_t)(oc->stagger >> 8));
     pattern.push_back((uint8_t)(pl->split ? 1 : 0));
     pattern.push_back((uint8_t)(pl->wave_bl ? 1 : 0));
     pattern.push_back(pl->seg_h.empty() ? 0 : 1);
@@ -862,8 +865,9 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "fft")) { if (value < 0 || value > 2) return FDES_EINVAL; c->opt_fft = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
-    if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 64 && value != 65 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "split")) { if (value < -1 || value > 1) return FDES_EINVAL; c->split = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "stagger")) { if (value < 0 || value > 1024) return FDES_EINVAL; c->stagger = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "walk")) { if (value < 1 || value > 8) return FDES_EINVAL; c->walk = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "pitch_pad")) { if (value < -1 || value > 1024 || (value > 0 && value % 2)) return FDES_EINVAL; c->pitch_pad = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
@@ -1027,8 +1031,12 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // or two lanes; 4096-point rows keep 512 threads (256 would cut the transposed-store segments to 16 bytes)
         // up to 1024^2 a pass is as long as its slowest workgroup: one row per thread, four rows per workgroup
         const bool small = m1 <= 1024 && m2 <= 1024;
-        if (c->pass_threads == 512) pl->wg = 512;
+        if ((c->pass_threads == 64 || c->pass_threads == 65) && (wave_pass_supported_len(m1) || wave_pass_supported_len(m2))) pl->wg = c->pass_threads; // one wave per row where the row length has such a kernel
+        else if (c->pass_threads == 512) pl->wg = 512;
         else if ((c->pass_threads == 1 || c->pass_threads == 513 || (c->pass_threads == 0 && small)) && m1 <= 2048 && m2 <= 2048) pl->wg = 1;
+        // 2048-point rows: one wave per row (fft_wave.hip: one LDS exchange per transform, no barrier inside it; headline
+        // +4 ... +6 % over 256 threads x 2 rows, A/B on one box); 4096-point rows: measured equal to 512 threads, which stay
+        else if (c->pass_threads == 0 && (m1 == 2048 || m2 == 2048) && m1 <= 2048 && m2 <= 2048) pl->wg = 64;
         else pl->wg = ok256 ? 256 : 512;
         // Slice-loop working set: the transient grids share buffers (A -> [P2] -> B; B -> [P3] -> C, C2; C | C2 -> [P4] -> E;
         // E, PSIH -> [P5] -> F; F -> [P6] -> PSIH: A, C and F are never live together, nor are B and E), and the
@@ -1530,6 +1538,7 @@ int fdes_fft2d_host(fdes_ctx* c, float* data, int m1, int m2, int inverse, int b
     Fft2D f;
     std::string ferr;
     if (f.create(m1, m2, backend, c->stream, &ferr) != 0) { f.destroy(); c->err = "FFT plan: " + ferr; return FDES_EGPU; }
+    if (c->pass_threads == 64 || c->pass_threads == 65) f.wg = c->pass_threads;
     float2* d = nullptr;
     const size_t bytes = sizeof(float2) * (size_t)m1 * m2;
     hipError_t e = hipMalloc((void**)&d, bytes);
@@ -1584,7 +1593,8 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
         A.nspecies = 1; A.species_stride = m12; A.scale = 1.f; A.mindim = n;
         A.walk = c->walk;
         if (c->bench_pitch) { A.pitch_in = n + c->bench_pitch; A.pitch_out = (store_t ? n * c->bench_tall : n) + c->bench_pitch; }
-        A.wg = c->pass_threads == 256 ? 256 : ((c->pass_threads == 513 || c->pass_threads == 1) && n <= 2048 ? 1 : 512);
+        A.wg = (c->pass_threads == 64 || c->pass_threads == 65) ? c->pass_threads : (c->pass_threads == 256 ? 256 : ((c->pass_threads == 513 || c->pass_threads == 1) && n <= 2048 ? 1 : 512));
+        A.stagger = c->stagger;
         if (c->bench_band) { // micro-benchmark of the band-limit bookkeeping: bit 0 live rows only, bit 1 dead loads, bit 2 dead stores
             A.band = n * n;
             A.live_rows_only = (c->bench_band & 1) ? 1 : 0;

@@ -25,6 +25,7 @@ struct Fft2D {
     // LDS kernels: twiddle tables of the two row lengths and a transposition scratch grid
     float2 *tw0x = nullptr, *tw1x = nullptr, *tw0y = nullptr, *tw1y = nullptr;
     float2* scratch = nullptr;
+    int wg = 512; // workgroup geometry of the LDS passes (PassArgs::wg)
 
     static bool lds_supported(int m1, int m2);
     int create(int m1, int m2, int opt, hipStream_t st, std::string* err);

@@ -68,11 +68,11 @@ hipError_t Fft2D::exec(float2* data, bool inverse, hipStream_t st)
         // pass 1: rows along x (length m1, m2 rows) -> scratch[kx][y]; pass 2: rows along y -> data[ky][kx]
         const int xf = inverse ? XF_INV : XF_FWD;
         PassArgs a;
-        a.in0 = data; a.out = scratch; a.tw0 = tw0x; a.tw1 = tw1x; a.nrows = m2;
+        a.in0 = data; a.out = scratch; a.tw0 = tw0x; a.tw1 = tw1x; a.nrows = m2; a.wg = wg;
         hipError_t e = lds_pass(m1, xf, MID_NONE, XF_NONE, true, a, st);
         if (e != hipSuccess) return e;
         PassArgs b;
-        b.in0 = scratch; b.out = data; b.tw0 = tw0y; b.tw1 = tw1y; b.nrows = m1;
+        b.in0 = scratch; b.out = data; b.tw0 = tw0y; b.tw1 = tw1y; b.nrows = m1; b.wg = wg;
         return lds_pass(m2, xf, MID_NONE, XF_NONE, true, b, st);
     }
     void* in[1] = {data};

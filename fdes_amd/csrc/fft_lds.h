@@ -55,7 +55,13 @@ struct PassArgs {
     size_t species_stride = 0;   // elements between species grids (in0 and gtab)
     float scale = 1.f;
     int mindim = 0;              // min(m1, m2) for the band limit
-    int wg = 512;                // workgroup geometry: 512 or 256 threads x 2 rows per thread, 1 = n/4 threads x 1 row (4 rows per workgroup)
+    int wg = 512;                // workgroup geometry: 512 or 256 threads x 2 rows per thread, 1 = n/4 threads x 1 row (4 rows per workgroup),
+                                 // 64 = one wave per row, 4 rows per workgroup (fft_wave.hip; 2048- and 4096-point rows, else as 256);
+                                 // 65 = the same as a software pipeline: one workgroup per CU walks the row groups, the next group's
+                                 //      operands are requested into a second register set before the current group is transformed
+    // one-wave-per-row passes: wave w of a CU's s-th workgroup starts (w + 4 s) * stagger * 64 cycles late (s taken as
+    // (workgroup index) / ncu: workgroups are dealt breadth first over the CUs; speed only)
+    int stagger = 0, ncu = 256;
     // Band limit bookkeeping (band = mindim^2 > 0 enables it): frequency index i is dead iff 9 i^2 > band, i.e. outside
     // the radial 2/3 mask whatever the other index is.  Dead rows/columns hold exact zeros that nobody needs to move.
     int band = 0;
@@ -83,6 +89,10 @@ bool lds_fft_supported_len(int n);
 int lds_fft_rows_per_block(int n, int wg);
 // fills host arrays (float2 as 2 floats) with the twiddle tables of length n: tw0[16*T], tw1[T]
 void lds_fft_twiddles(int n, float* tw0, float* tw1);
+
+// one-wave-per-row passes (fft_wave.hip)
+bool wave_pass_supported_len(int n);
+hipError_t wave_pass(int n, int pre, int mid, int post, bool store_transposed, const PassArgs& a, hipStream_t st);
 
 // Launch one pass over all rows. n = row length, kinds select the template instantiation.
 hipError_t lds_pass(int n, int pre, int mid, int post, bool store_transposed, const PassArgs& a, hipStream_t st);

@@ -38,253 +38,7 @@ namespace {
 #define FDES_EXP_NOLDS 0
 #endif
 
-constexpr float C1 = 0.923879532511286756f; // cos(pi/8)
-constexpr float S1 = 0.382683432365089772f; // sin(pi/8)
-constexpr float C2 = 0.707106781186547524f; // cos(pi/4)
-
-// Complex values are native 2-vectors (clang ext_vector_type), not HIP's float2 struct: the backend then sees
-// <2 x float> adds / fmas and emits v_pk_add_f32 / v_pk_fma_f32 with op_sel / neg modifiers, instead of re-discovering
-// pairs by SLP (which packed unrelated scalars and cost a v_mov per four arithmetic instructions).
-typedef float cf __attribute__((ext_vector_type(2)));
-// (Exchange reads: where two of a thread's reads are less than 2 KiB apart the compiler merges them into ds_read2_b64.
-// Keeping them apart with `volatile` was measured: P4 18.3 -> 21.1 us, the two-slice transmission pass 35 -> 60 us -
-// the ordering constraints of volatile cost far more than the narrower instruction.)
-#define float2 cf
-#define make_float2(x, y) (cf{(x), (y)})
-__device__ __forceinline__ cf cmul(cf a, cf b) { return __builtin_elementwise_fma(a.yx, cf{-b.y, b.y}, a * b.xx); }
-// a * conj(b)
-__device__ __forceinline__ cf cmulc(cf a, cf b) { return __builtin_elementwise_fma(a.yx, cf{b.y, -b.y}, a * b.xx); }
-// multiply by the forward twiddle w (INV = false) or its conjugate (INV = true)
-template <bool INV> __device__ __forceinline__ float2 twmul(float2 a, float2 w) { return INV ? cmulc(a, w) : cmul(a, w); }
-// The same products for a factor that is only known at run time (stage twiddles, table values, the second operand of a
-// product).  The compiler cannot put the sign of ONE half of (-b.y, b.y) into the instruction's neg_lo / neg_hi modifier
-// and builds that vector in registers instead (v_xor + 2 v_mov per factor: 290 of P5's 2460 vector instructions); with
-// the modifier written out a product is the two packed instructions it should be.  Same operations, same rounding.
-#ifndef FDES_ASM_CMUL
-#define FDES_ASM_CMUL 1
-#endif
-__device__ __forceinline__ cf cmul_rt(cf a, cf b)
-{
-#if FDES_ASM_CMUL
-    const cf t = a * b.xx;
-    cf r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-    return r;
-#else
-    return cmul(a, b);
-#endif
-}
-__device__ __forceinline__ cf cmulc_rt(cf a, cf b)
-{
-#if FDES_ASM_CMUL
-    const cf t = a * b.xx;
-    cf r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-    return r;
-#else
-    return cmulc(a, b);
-#endif
-}
-template <bool INV> __device__ __forceinline__ float2 twmul_rt(float2 a, float2 w) { return INV ? cmulc_rt(a, w) : cmul_rt(a, w); }
-// multiply by -i (forward) / +i (inverse)
-template <bool INV> __device__ __forceinline__ float2 mul_mi(float2 a) { return a.yx * (INV ? cf{-1.f, 1.f} : cf{1.f, -1.f}); }
-// b + (-i) a (forward) / b + i a (inverse), and b - (...): one packed fma each, the swap rides on op_sel
-template <bool INV> __device__ __forceinline__ float2 add_mi(float2 b, float2 a) { return __builtin_elementwise_fma(a.yx, (INV ? cf{-1.f, 1.f} : cf{1.f, -1.f}), b); }
-template <bool INV> __device__ __forceinline__ float2 sub_mi(float2 b, float2 a) { return __builtin_elementwise_fma(a.yx, (INV ? cf{1.f, -1.f} : cf{-1.f, 1.f}), b); }
-// Product t * psi and psi * P (multiplyElementwise, src/complexMath.cu:44-62).  The reference uses the 3-multiply form
-// k = a (c + d), re = k - d (a + b), im = k + c (b - a): 8 dependent scalar operations per pixel.  The default here is
-// the 4-multiply form as one packed multiply + one packed FMA (2 instructions; no worse conditioned than the 3-multiply
-// form, which cancels k against its partner); -DFDES_CMUL3=1 restores the reference's operation order.
-#ifndef FDES_CMUL3
-#define FDES_CMUL3 0
-#endif
-__device__ __forceinline__ float2 cmul3(float2 f0, float2 f1)
-{
-#if FDES_CMUL3
-    const float a = f0.x, b = f0.y;
-    float c = f1.x, d = f1.y;
-    const float k = a * (c + d);
-    d *= a + b;
-    c *= b - a;
-    return make_float2(k - d, k + c);
-#else
-    return cmul_rt(f0, f1);
-#endif
-}
-
-template <bool INV> __device__ __forceinline__ void r2(float2& x0, float2& x1)
-{
-    const float2 t = x0 - x1;
-    x0 = x0 + x1;
-    x1 = t;
-}
-
-template <bool INV> __device__ __forceinline__ void r4(float2& x0, float2& x1, float2& x2, float2& x3)
-{
-    const float2 t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, d = x1 - x3;
-    x0 = t0 + t2;
-    x1 = add_mi<INV>(t1, d);
-    x2 = t0 - t2;
-    x3 = sub_mi<INV>(t1, d);
-}
-
-// in-place 8-point DFT, natural order in and out
-template <bool INV> __device__ __forceinline__ void r8(float2& a0, float2& a1, float2& a2, float2& a3, float2& a4, float2& a5, float2& a6,
-                                                       float2& a7)
-{
-    // j = 2 j1 + j0: radix-4 over j1 for j0 = 0 (a0,a2,a4,a6) and j0 = 1 (a1,a3,a5,a7)
-    r4<INV>(a0, a2, a4, a6); // c[0][k0] in a0,a2,a4,a6
-    r4<INV>(a1, a3, a5, a7); // c[1][k0] in a1,a3,a5,a7
-    // twiddle c[1][k0] *= w8^k0
-    a3 = twmul<INV>(a3, make_float2(C2, -C2));
-    a7 = twmul<INV>(a7, make_float2(-C2, -C2));
-    // b[k0 + 4 k1] = c[0][k0] +- c[1][k0]   (k0 = 2: the twiddle is -+i)
-    float2 b0 = a0 + a1, b4 = a0 - a1, b1 = a2 + a3, b5 = a2 - a3, b2 = add_mi<INV>(a4, a5), b6 = sub_mi<INV>(a4, a5), b3 = a6 + a7,
-           b7 = a6 - a7;
-    a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
-}
-
-// in-place 16-point DFT, natural order in and out
-template <bool INV> __device__ __forceinline__ void r16(float2 (&a)[16])
-{
-    // j = 4 j1 + j0: radix-4 over j1 -> c[j0][k0] left at a[4 k0 + j0]
-#pragma unroll
-    for (int j0 = 0; j0 < 4; j0++) r4<INV>(a[j0], a[4 + j0], a[8 + j0], a[12 + j0]);
-    // twiddles w16^(j0 k0)
-    a[4 + 1] = twmul<INV>(a[4 + 1], make_float2(C1, -S1));   // m = 1
-    a[4 + 2] = twmul<INV>(a[4 + 2], make_float2(C2, -C2));   // m = 2
-    a[4 + 3] = twmul<INV>(a[4 + 3], make_float2(S1, -C1));   // m = 3
-    a[8 + 1] = twmul<INV>(a[8 + 1], make_float2(C2, -C2));   // m = 2
-    a[8 + 2] = mul_mi<INV>(a[8 + 2]);                        // m = 4
-    a[8 + 3] = twmul<INV>(a[8 + 3], make_float2(-C2, -C2));  // m = 6
-    a[12 + 1] = twmul<INV>(a[12 + 1], make_float2(S1, -C1)); // m = 3
-    a[12 + 2] = twmul<INV>(a[12 + 2], make_float2(-C2, -C2)); // m = 6
-    a[12 + 3] = twmul<INV>(a[12 + 3], make_float2(-C1, S1)); // m = 9
-    // radix-4 over j0 for each k0: b[k0 + 4 k1] left at a[4 k0 + k1]
-#pragma unroll
-    for (int k0 = 0; k0 < 4; k0++) r4<INV>(a[4 * k0], a[4 * k0 + 1], a[4 * k0 + 2], a[4 * k0 + 3]);
-    // 4x4 transpose of the register indices -> natural order
-    float2 t;
-#define SWP(i, j) t = a[i]; a[i] = a[j]; a[j] = t;
-    SWP(1, 4) SWP(2, 8) SWP(3, 12) SWP(6, 9) SWP(7, 13) SWP(11, 14)
-#undef SWP
-}
-
-// sin/cos with a two-constant Cody-Waite reduction (|x| < ~1e4: projected-potential phases are a few
-// radians) and degree-9/8 polynomials on [-pi/4, pi/4]; abs. error < 2e-7.  The library sincosf
-// carries a Payne-Hanek slow path whose register footprint made the fused pass spill.
-__device__ __forceinline__ void sincos_cw(float x, float& s, float& c)
-{
-    const float kf = rintf(x * 0.636619772f);
-    const int k = (int)kf;
-    float r = fmaf(-kf, 1.57079601e+00f, x);
-    r = fmaf(-kf, 3.13916473e-07f, r);
-    r = fmaf(-kf, 5.39030253e-15f, r);
-    const float r2 = r * r;
-    float sp = 2.75573192e-6f;
-    sp = fmaf(sp, r2, -1.98412701e-4f);
-    sp = fmaf(sp, r2, 8.33333377e-3f);
-    sp = fmaf(sp, r2, -1.66666672e-1f);
-    const float sn = fmaf(r * r2, sp, r);
-    float cp = 2.48015876e-5f;
-    cp = fmaf(cp, r2, -1.38888892e-3f);
-    cp = fmaf(cp, r2, 4.16666679e-2f);
-    cp = fmaf(cp, r2, -0.5f);
-    const float cs = fmaf(cp, r2, 1.0f);
-    const float s_ = (k & 1) ? cs : sn;
-    const float c_ = (k & 1) ? sn : cs;
-    s = (k & 2) ? -s_ : s_;
-    c = ((k + 1) & 2) ? -c_ : c_;
-}
-
-// Outside that range (|x| > kSincosFast: no physical specimen, but nothing in the input format forbids it) the
-// reduction is done in double precision against a two-word pi/2: exact to < 1e-7 rad up to |x| ~ 1e9, no Payne-Hanek
-// tables, a handful of registers.  The pass kernels test their 32 phases once and take this path as a whole.
-constexpr float kSincosFast = 1.0e3f;
-__device__ __forceinline__ void sincos_wide(float x, float& s, float& c)
-{
-    const double xd = (double)x;
-    const double kd = rint(xd * 0.63661977236758134308);
-    double rd = fma(-kd, 1.57079632679489655800e+00, xd);
-    rd = fma(-kd, 6.12323399573676603587e-17, rd);
-    const int k = (int)(long long)kd; // |kd| < 2^31 for |x| < 3.3e9; beyond that float phases carry no information
-    const float r = (float)rd;
-    const float r2 = r * r;
-    float sp = 2.75573192e-6f;
-    sp = fmaf(sp, r2, -1.98412701e-4f);
-    sp = fmaf(sp, r2, 8.33333377e-3f);
-    sp = fmaf(sp, r2, -1.66666672e-1f);
-    const float sn = fmaf(r * r2, sp, r);
-    float cp = 2.48015876e-5f;
-    cp = fmaf(cp, r2, -1.38888892e-3f);
-    cp = fmaf(cp, r2, 4.16666679e-2f);
-    cp = fmaf(cp, r2, -0.5f);
-    const float cs = fmaf(cp, r2, 1.0f);
-    const float s_ = (k & 1) ? cs : sn;
-    const float c_ = (k & 1) ? sn : cs;
-    s = (k & 2) ? -s_ : s_;
-    c = ((k + 1) & 2) ? -c_ : c_;
-}
-template <bool WIDE> __device__ __forceinline__ void sincos_sel(float x, float& s, float& c)
-{
-    if constexpr (WIDE) sincos_wide(x, s, c);
-    else sincos_cw(x, s, c);
-}
-
-// v -> f(v) on every element a thread holds, with the fast sine/cosine while all of its phases are small (the only
-// case a physical specimen produces) and the wide-range one otherwise; `mag` returns |phase| of an element.
-template <int NRV, class F, class M> __device__ __forceinline__ void expiv_all(cf (&a)[NRV][16], F f, M mag)
-{
-    float big = 0.f;
-#pragma unroll
-    for (int h = 0; h < NRV; h++)
-#pragma unroll
-        for (int l = 0; l < 16; l++) big = fmaxf(big, mag(a[h][l]));
-    if (__builtin_expect(big <= kSincosFast, 1)) {
-#pragma unroll
-        for (int h = 0; h < NRV; h++)
-#pragma unroll
-            for (int l = 0; l < 16; l++) a[h][l] = f(a[h][l], std::false_type{});
-    } else {
-#pragma unroll
-        for (int h = 0; h < NRV; h++) // unrolled as well: a runtime index would send the whole register array to scratch
-#pragma unroll
-            for (int l = 0; l < 16; l++) a[h][l] = f(a[h][l], std::true_type{});
-    }
-}
-
-// t = exp(-imPot v) (cos v, sin v) for v = a.x (potential2Transmission, src/multisliceSimulation.cu:41-52, with the
-// absorptive part V.y = imPot V.x of src/crystalMaker.cu:101).  Without absorption (imPot = 0, a uniform value) the
-// exponential is exactly 1 and is not evaluated.
-template <int NRV> __device__ __forceinline__ void pair_transmission(cf (&a)[NRV][16], const float impot)
-{
-    if (impot == 0.f) {
-        expiv_all(a, [&](cf w, auto wide) {
-            float sn, cs;
-            sincos_sel<decltype(wide)::value>(w.x, sn, cs);
-            return cf{cs, sn};
-        }, [](cf w) { return fabsf(w.x); });
-    } else {
-        expiv_all(a, [&](cf w, auto wide) {
-            const float v = w.x;
-            float sn, cs;
-            const float e = __expf(-(v * impot));
-            sincos_sel<decltype(wide)::value>(v, sn, cs);
-            return cf{e * cs, e * sn};
-        }, [](cf w) { return fabsf(w.x); });
-    }
-}
-
-__device__ __forceinline__ int iwc(int i, int m) { return (i > m / 2) ? i - m : i; } // iwCoordIp
-// outside the radial 2/3 band limit for every value of the other index (zeroHighFreq: 9 (i1^2 + i2^2) > mindim^2)
-__host__ __device__ __forceinline__ bool dead_index(int i, int band) { return 9 * i * i > band; }
-// largest |i| that is still live
-inline int live_limit(int band)
-{
-    int L = 0;
-    while (!dead_index(L + 1, band)) L++;
-    return L;
-}
+#include "fft_dev.inc"
 
 // Workgroup geometries (template parameter WG): even -> WG threads x 2 rows per thread (256: default up to 2048
 // points, 512: 4096 points); odd -> (WG - 1) threads x 1 row per thread, instantiated as N / 4 + 1 only, i.e. four
@@ -1024,7 +778,11 @@ template <int N> hipError_t dispatch_wg(int pre, int mid, int post, bool st_t, c
 } // namespace
 
 bool lds_fft_supported_len(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
-int lds_fft_rows_per_block(int n, int wg) { return wg == 1 ? 4 : (wg == 256 ? 256 * 2 : 512 * 2) * 16 / n; }
+int lds_fft_rows_per_block(int n, int wg)
+{
+    if (wg == 64 || wg == 65) return wave_pass_supported_len(n) ? 4 : 256 * 2 * 16 / n;
+    return wg == 1 ? 4 : (wg == 256 ? 256 * 2 : 512 * 2) * 16 / n;
+}
 
 void lds_fft_twiddles(int n, float* tw0, float* tw1)
 {
@@ -1051,6 +809,10 @@ hipError_t lds_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
     if (a.band > 0) {
         a.band_L = live_limit(a.band);
         if (a.band_L != n / 3) a.skip_dead_loads = 0; // the kernel's column classes assume the band of a square grid
+    }
+    if (a.wg == 64 || a.wg == 65) {
+        if (wave_pass_supported_len(n)) return wave_pass(n, pre, mid, post, st_t, a, st);
+        a.wg = 256; // shorter rows: two rows per thread
     }
     switch (n) {
     case 256: return dispatch_wg<256>(pre, mid, post, st_t, a, st);

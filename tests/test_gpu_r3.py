@@ -71,3 +71,65 @@ def test_bench_launch_path_against_oracle_at_headline_size(oracle):
     print(f"[parity] bench path (C3 2048^2 x 256, frPh=2, two lanes + graph): E(gpu vs cpu_f32) = {e:.3e}")
     assert e <= 5e-5
     assert np.abs(img - r32).max() <= 1e-3 * np.abs(r32).max()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one-wave-per-row passes (fft_wave.hip): engine option pass_threads = 64, 2048- and 4096-point rows
+# ------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("threads", [64, 65])
+@pytest.mark.parametrize("shape", [(2048, 2048), (4096, 4096), (2048, 4096), (1024, 2048)])
+def test_wave_fft_against_numpy(shape, threads):
+    """The row FFT with one wave per row (radix-32 / radix-64 butterflies over the registers, one LDS exchange, the
+    radix-2 across lane halves by v_permlane32_swap at 2048 points) as a 2-D transform against numpy; 1024-point rows
+    fall back to the two-rows-per-thread kernels."""
+    eng = fdes_amd.Engine(0, pass_threads=threads)
+    rng = np.random.default_rng(11)
+    f = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    for inv in (False, True):
+        out, used = eng.fft2(f, inv, backend=2)
+        assert used == 2
+        ref = np.fft.ifft2(f.astype(np.complex128)) * f.size if inv else np.fft.fft2(f.astype(np.complex128))
+        e = relerr(out, ref)
+        print(f"[parity] wave fft {shape} inv={inv}: rel L2 {e:.3e}")
+        assert e < 5e-7
+    eng.close()
+
+
+@pytest.mark.parametrize("threads", [64, 65])
+@pytest.mark.parametrize("m,nz,stagger", [(2048, 1, 0), (2048, 2, 16), (4096, 1, 0), (4096, 2, 8)])
+def test_wave_passes_slice_loop(oracle, m, nz, stagger, threads):
+    """Every pass of the slice loop on the one-wave-per-row kernels (P1' atoms, P2 with one and two species, the two-slice
+    P3, P4, P5, P6, enter / leave), with and without the staggered start: exit wave after an odd number of slices and
+    the potential of both members of a pair against the float64 oracle.  phaseGrating src/crystalMaker.cu:507-536,
+    forwardPropagation src/multisliceSimulation.cu:538-549."""
+    hp, at = S.case_tiny(m=m, m3=5 if m == 2048 else 3, nz=nz, nat=300, tilt=True, seed=41 + nz)
+    fdes_amd.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    eng = fdes_amd.Engine(0, pass_threads=threads, skip_empty=0, stagger=stagger)
+    pl = eng.plan(hp, at)
+    assert pl.fft_backend() == 2
+    psi = pl.tap_wave(0, 0)
+    ref = oracle.wave(q, at, 0, 0, prec="f64")
+    check(psi, ref, oracle.wave(q, at, 0, 0, prec="f32"), 1e-5, f"wave passes: exit wave {m}^2 nz={nz} stagger={stagger}")
+    xyz = oracle.config_coords(q, at, 0, -1)
+    for s in (1, 2):
+        V = pl.tap_potential(0, 0, s)
+        check(V, oracle.phase_grating(q, at, xyz, s, "f64"), None, 1e-5, f"wave passes: potential s={s} {m}^2 nz={nz}")
+    pl.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("threads", [64, 65])
+def test_wave_passes_equal_lanes_graph_and_empty_slices(oracle, threads):
+    """One-wave-per-row passes through the whole driver at 2048^2: two lanes, graph replay, frozen phonons, runs of
+    empty slices (P^n steps) - image against the float32 oracle."""
+    hp, at = S.case_tiny(m=2048, m3=8, nz=2, nat=400, frPh=3, tilt=True, seed=5, zfrac=0.25)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0, pass_threads=threads, stagger=12 if threads == 64 else 0)
+    img = eng.build_measurements(hp, at)["image"]
+    eng.close()
+    r64 = oracle.build_measurements(hp, at, prec="f64")["image"]
+    e = relerr(img, r64)
+    print(f"[parity] wave passes, driver 2048^2 frPh=3 with empty slices: E = {e:.3e}")
+    assert e <= 1e-5

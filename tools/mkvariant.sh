@@ -6,7 +6,8 @@ name=$1; shift
 C=$(dirname "$0")/../fdes_amd/csrc
 V=$C/build/variants
 mkdir -p $V
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-result -munsafe-fp-atomics "$@" -I$C -c ${SRC:-$C/fft_lds.hip} -o $V/fft_lds_$name.o
-objs=$(ls $C/build/*.o | grep -v fft_lds.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $V/lib_$name.so $objs $V/fft_lds_$name.o -L/opt/rocm/lib -lrocfft -ldl -lpthread -Wl,-rpath,/opt/rocm/lib
+OBJ=${OBJ:-fft_lds}   # the translation unit that is rebuilt (OBJ=fft_wave for the one-wave-per-row passes)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-result -munsafe-fp-atomics "$@" -I$C -c ${SRC:-$C/$OBJ.hip} -o $V/${OBJ}_$name.o
+objs=$(ls $C/build/*.o | grep -v "/$OBJ.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $V/lib_$name.so $objs $V/${OBJ}_$name.o -L/opt/rocm/lib -lrocfft -ldl -lpthread -Wl,-rpath,/opt/rocm/lib
 echo built $V/lib_$name.so
