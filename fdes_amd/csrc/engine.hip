@@ -55,6 +55,7 @@ struct fdes_ctx {
     int stagger = 0;      // one-wave-per-row passes: start delay between the waves of a CU, in units of 64 cycles (0: none)
     int walk = 1;         // every pass is launched in this many parts (2: a part takes half of the workgroup slots, two lanes' passes share every CU)
     int pitch_pad = -1;   // elements added to every row of the fused loop's grids; -1 auto: 32 for 2048-point rows, 64 from 4096 on
+    int deterministic = 1; // the deposit of the generic (rocFFT) path and of the potential output adds the atoms in sorted order through LDS (bit-reproducible); 0: global float atomics as the reference
     int peer_copy = 1;    // 0: fdes_plan_accumulate_from stages partial sums through host memory instead of a peer copy (the fallback path, forced)
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
     // plans are expensive to create: one per grid size AND requested back-end (option "fft" may change between plans)
@@ -271,7 +272,7 @@ int config_atoms(fdes_plan* pl, int k, int j)
     else
         HIPCHK(c, hipMemcpyAsync(pl->xyzFP_d, pl->xyzK_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, c->stream));
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
-    HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, pl->fused, c->stream));
+    HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, pl->fused || owner_ctx(pl)->deterministic, c->stream));
     fdes_plan* tp = pl->top ? pl->top : pl;
     constexpr int kDenseAfter = 8, kDenseRecheck = 64;
     bool ask = pl->fused && owner_ctx(pl)->skip_empty;
@@ -310,6 +311,8 @@ int phase_grating(fdes_plan* pl, const float* xyz, const BinGeom& g, int s)
     kp.m3 = g.m3;
     kp.d3 = g.d3;
     for (int z = 0; z < pl->nZ; z++) {
+        if (owner_ctx(pl)->deterministic) HIPCHK(c, geom_deposit_tile(pl->D, pl->bins, s * pl->nZ + z, -1, true, pl->p.imPot, g, c->stream));
+        else
         HIPCHK(c, geom_deposit(pl->D, xyz, pl->occ_d, pl->bins, s * pl->nZ + z, g, pl->p.imPot, pl->deposit_blocks, c->stream));
         HIPCHK(c, fft_exec(pl,pl->D, false, c->stream));
         HIPCHK(c, k_filter_accum(pl->VH, pl->D, kp, pl->kz[z], z == 0, c->stream));
@@ -326,6 +329,8 @@ int phase_grating_pair(fdes_plan* pl, const float* xyz, const BinGeom& g, int s0
     fdes_ctx* c = pl->ctx;
     for (int z = 0; z < pl->nZ; z++) {
         const int k0 = s0 * pl->nZ + z, k1 = (s0 + 1 < g.m3) ? (s0 + 1) * pl->nZ + z : -1;
+        if (owner_ctx(pl)->deterministic) HIPCHK(c, geom_deposit_tile(pl->D, pl->bins, k0, k1, false, 0.f, g, c->stream));
+        else
         HIPCHK(c, geom_deposit_pair(pl->D, xyz, pl->occ_d, pl->bins, k0, k1, g, pl->deposit_blocks, c->stream));
         HIPCHK(c, fft_exec(pl, pl->D, false, c->stream));
         HIPCHK(c, k_filter_accum_tab(pl->VH, pl->D, pl->GT + (size_t)z * pl->m12, pl->m12, z == 0, c->stream));
@@ -878,6 +883,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "skip_empty")) { c->skip_empty = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "lanes")) { if (value < 0 || value > 4) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "deterministic")) { c->deterministic = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "peer_copy")) { c->peer_copy = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "probe_stride")) { c->probe_stride = (int)value; return FDES_OK; }
     return FDES_EINVAL;
@@ -980,6 +986,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLCHK(dmalloc(c, &pl->bins.seg, (size_t)pl->bins_cap_keys + 2));
     PLCHK(dmalloc(c, &pl->bins.recs, (size_t)nAt));
     PLCHK(dmalloc(c, &pl->bins.recs_sorted, (size_t)nAt));
+    PLCHK(dmalloc(c, &pl->bins.rowstart, (size_t)m3max * pl->nZ * (size_t)(pl->p.m2 + 1))); // first sorted position of every (slice, species, row)
     pl->bins.tmp_bytes = geom_sort_temp_bytes(nAt);
     PLHIP(hipMalloc(&pl->bins.tmp, pl->bins.tmp_bytes > 0 ? pl->bins.tmp_bytes : 16));
     {   // enough blocks for an average segment, capped; the kernel strides over the rest
@@ -1085,7 +1092,6 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             PLCHK(dmalloc(c, &pl->PT, (size_t)pl->p.m1 + (size_t)pl->p.m2));
             PLCHK(dmalloc(c, &pl->GT, pl->gsz * (size_t)pl->nZ));
         }
-        PLCHK(dmalloc(c, &pl->bins.rowstart, (size_t)pl->p.m3 * pl->nZ * (size_t)(pl->p.m2 + 1)));
         // dead (band-limited) rows / columns of these grids are never written again: they must read as zero
         for (float2* q : {pl->C, pl->C2, pl->E, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->gsz, c->stream));
         if (!pl->tables_shared) {
@@ -1413,7 +1419,7 @@ int fdes_plan_potential(fdes_plan* pl, int s_lo, int s_hi, float* potential)
     const float inv = 1.f / (float)pl->ratio;
     BinGeom g{pl->p.m1, pl->p.m2, (int)(((float)pl->p.m3) * inv), pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3 / inv};
     if (s_lo < 0 || s_hi > g.m3 || s_lo > s_hi) return FDES_EINVAL;
-    HIPCHK(c, geom_bin_atoms(pl->xyzTO_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, false, c->stream));
+    HIPCHK(c, geom_bin_atoms(pl->xyzTO_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, owner_ctx(pl)->deterministic != 0, c->stream));
     for (int s = s_lo; s < s_hi; s++) {
         RC(phase_grating(pl, pl->xyzTO_d, g, s));
         HIPCHK(c, hipMemcpyAsync(potential + 2 * pl->m12 * (size_t)(s - s_lo), pl->VH, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream));

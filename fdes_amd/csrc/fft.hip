@@ -11,15 +11,17 @@ namespace fdes {
 
 bool Fft2D::lds_supported(int m1, int m2)
 {
-    if (!lds_fft_supported_len(m1) || !lds_fft_supported_len(m2)) return false;
+    if (!(lds_fft_supported_len(m1) || gen_pass_supported_len(m1)) || !(lds_fft_supported_len(m2) || gen_pass_supported_len(m2))) return false;
     return (m2 % lds_fft_rows_per_block(m1, 512) == 0) && (m1 % lds_fft_rows_per_block(m2, 512) == 0);
 }
 
 static int upload_twiddles(int n, float2** tw0, float2** tw1, std::string* err)
 {
+    const bool gen = gen_pass_supported_len(n); // mixed-radix passes: tw0 = the n roots of unity, tw1 unused
     const int T = n / 16, P = T / 16 > 0 ? T / 16 : 1;
-    std::vector<float> h0(2 * 16 * (size_t)T), h1(2 * 16 * (size_t)P);
-    lds_fft_twiddles(n, h0.data(), h1.data());
+    std::vector<float> h0(gen ? 2 * (size_t)n : 2 * 16 * (size_t)T), h1(2 * 16 * (size_t)P);
+    if (gen) gen_pass_twiddles(n, h0.data());
+    else lds_fft_twiddles(n, h0.data(), h1.data());
     if (hipMalloc((void**)tw0, h0.size() * sizeof(float)) != hipSuccess || hipMalloc((void**)tw1, h1.size() * sizeof(float)) != hipSuccess ||
         hipMemcpy(*tw0, h0.data(), h0.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(*tw1, h1.data(), h1.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
@@ -34,7 +36,7 @@ int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err)
     m1 = m1_;
     m2 = m2_;
     const bool lds_ok = lds_supported(m1, m2);
-    if (opt == 2 && !lds_ok) { if (err) *err = "hand-written FFT needs power-of-two grids of 256..4096 points"; return -1; }
+    if (opt == 2 && !lds_ok) { if (err) *err = "hand-written FFT needs grid lengths 256 ... 4096 that are powers of two, or 2^a 3^b 5^c up to 2048"; return -1; }
     backend = (opt == 1 || !lds_ok) ? 1 : 2;
     if (backend == 2) {
         if (upload_twiddles(m1, &tw0x, &tw1x, err)) return -1;

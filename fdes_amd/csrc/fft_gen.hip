@@ -1,0 +1,501 @@
+// fft_gen.hip — LDS-resident row passes for grids that are not a power of two (gfx950).
+//
+// cuFFT serves any size alike (src/paramStructure.cu:676-679) and the reference's own examples use 320-, 800- and
+// 1000-point grids (bin/dataFDES.cnf; bin/test.qsc: m = 2 nx, src/rwQsc.cu:943-948; ExampleSpecimens/Si_001_11k_cnf).
+// The kernels of fft_lds.hip / fft_wave.hip keep a row in registers and are unrolled per power-of-two length; here the
+// same pass structure (coalesced row loads -> [row FFT] -> point-wise operation -> [row FFT] -> natural or transposed
+// store, fft_lds.h) runs with the rows in LDS and the length as a run-time value, for any N = 2^a 3^b 5^c in
+// [256, 2048]: mixed-radix Stockham stages (radices 10, 8, 5, 4, 3, 2) between two LDS images of the row tile, one
+// work item per butterfly, twiddles from a table of the N-th roots of unity (double-precision values rounded once;
+// every twiddle is ONE table entry), results in natural order after the last stage.  One workgroup = R rows (4 above
+// 512 points, 8 up to it: 32- resp. 64-byte segments in the transposed store).  The slice loop of the engine then runs
+// these sizes with the same 4.5 launches per slice as the power-of-two grids instead of rocFFT + point-wise kernels.
+#include "fft_lds.h"
+#include "geometry.h"
+
+#include <atomic>
+#include <cmath>
+#include <type_traits>
+
+namespace fdes {
+
+namespace {
+
+#include "fft_dev.inc"
+
+struct GenFac {
+    int n = 0;       // row length
+    int rows = 0;    // rows per workgroup
+    int nf = 0;      // stages
+    int radix[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+constexpr int kGenThreads = 256;
+
+// s = +1 forward, -1 inverse: multiply by -i (forward) / +i (inverse)
+__device__ __forceinline__ cf mi_s(cf a, float s) { return cf{a.y * s, -a.x * s}; }
+// a * (c - i s_ sgn): the constant root of unity exp(-i phi) (forward) / exp(+i phi) (inverse), c = cos phi, sn = sin phi
+__device__ __forceinline__ cf rot_s(cf a, float c, float sn, float s) { return cf{a.x * c + a.y * (sn * s), a.y * c - a.x * (sn * s)}; }
+
+__device__ __forceinline__ void dft2(cf (&x)[10])
+{
+    const cf t = x[0] - x[1];
+    x[0] = x[0] + x[1];
+    x[1] = t;
+}
+__device__ __forceinline__ void dft3(cf (&x)[10], float s)
+{
+    const cf t1 = x[1] + x[2];
+    const cf t2 = x[0] - t1 * 0.5f;
+    const cf t3 = mi_s((x[1] - x[2]) * 0.866025403784438647f, s);
+    x[0] = x[0] + t1;
+    x[1] = t2 + t3;
+    x[2] = t2 - t3;
+}
+__device__ __forceinline__ void dft4(cf (&x)[10], float s)
+{
+    const cf a = x[0] + x[2], b = x[0] - x[2], c = x[1] + x[3], d = mi_s(x[1] - x[3], s);
+    x[0] = a + c;
+    x[1] = b + d;
+    x[2] = a - c;
+    x[3] = b - d;
+}
+__device__ __forceinline__ void dft5_(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4, float s)
+{
+    constexpr float c1 = 0.309016994374947424f, c2 = -0.809016994374947424f; // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr float s1 = 0.951056516295153572f, s2 = 0.587785252292473129f;  // sin(2 pi / 5), sin(4 pi / 5)
+    const cf a1 = x1 + x4, a2 = x2 + x3, b1 = x1 - x4, b2 = x2 - x3;
+    const cf m1 = x0 + a1 * c1 + a2 * c2, m2 = x0 + a1 * c2 + a2 * c1;
+    const cf n1 = mi_s(b1 * s1 + b2 * s2, s), n2 = mi_s(b1 * s2 - b2 * s1, s);
+    x0 = x0 + a1 + a2;
+    x1 = m1 + n1;
+    x4 = m1 - n1;
+    x2 = m2 + n2;
+    x3 = m2 - n2;
+}
+__device__ __forceinline__ void dft5(cf (&x)[10], float s) { dft5_(x[0], x[1], x[2], x[3], x[4], s); }
+__device__ __forceinline__ void dft8(cf (&x)[10], float s)
+{
+    // two radix-4 over the even / odd inputs, then the radix-2 level with W_8^k
+    cf e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
+    {
+        const cf a = e0 + e2, b = e0 - e2, c = e1 + e3, d = mi_s(e1 - e3, s);
+        e0 = a + c; e1 = b + d; e2 = a - c; e3 = b - d;
+    }
+    {
+        const cf a = o0 + o2, b = o0 - o2, c = o1 + o3, d = mi_s(o1 - o3, s);
+        o0 = a + c; o1 = b + d; o2 = a - c; o3 = b - d;
+    }
+    constexpr float h = 0.707106781186547524f;
+    o1 = rot_s(o1, h, h, s);
+    o2 = mi_s(o2, s);
+    o3 = rot_s(o3, -h, h, s);
+    x[0] = e0 + o0; x[4] = e0 - o0;
+    x[1] = e1 + o1; x[5] = e1 - o1;
+    x[2] = e2 + o2; x[6] = e2 - o2;
+    x[3] = e3 + o3; x[7] = e3 - o3;
+}
+__device__ __forceinline__ void dft10(cf (&x)[10], float s)
+{
+    // X[k] = E[k mod 5] + W_10^k O[k mod 5]: two radix-5 over the even / odd inputs
+    cf e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], e4 = x[8], o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7], o4 = x[9];
+    dft5_(e0, e1, e2, e3, e4, s);
+    dft5_(o0, o1, o2, o3, o4, s);
+    o1 = rot_s(o1, 0.809016994374947424f, 0.587785252292473129f, s);  // W_10^1
+    o2 = rot_s(o2, 0.309016994374947424f, 0.951056516295153572f, s);  // W_10^2
+    o3 = rot_s(o3, -0.309016994374947424f, 0.951056516295153572f, s); // W_10^3
+    o4 = rot_s(o4, -0.809016994374947424f, 0.587785252292473129f, s); // W_10^4
+    x[0] = e0 + o0; x[5] = e0 - o0;
+    x[1] = e1 + o1; x[6] = e1 - o1;
+    x[2] = e2 + o2; x[7] = e2 - o2;
+    x[3] = e3 + o3; x[8] = e3 - o3;
+    x[4] = e4 + o4; x[9] = e4 - o4;
+}
+
+// One Stockham stage of radix RX over the R rows of the tile: work item = (row, butterfly j), inputs src[j + i N/RX],
+// twiddle W_N^(i k N / (Ns RX)) with k = j mod Ns, outputs dst[(j / Ns) Ns RX + k + i Ns].
+template <int RX>
+__device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __restrict__ dst, const cf* __restrict__ twl, const int N, const int R,
+                                          const int Ns, const float s)
+{
+    const int nb = N / RX;          // butterflies per row
+    const int tws = N / (Ns * RX);  // table step of this stage's twiddle
+    for (int wi = threadIdx.x; wi < R * nb; wi += kGenThreads) {
+        const int row = wi / nb, j = wi - row * nb;
+        const int k = j % Ns;
+        const cf* __restrict__ in = src + row * N + j;
+        cf x[10];
+#pragma unroll
+        for (int i = 0; i < RX; i++) x[i] = in[i * nb];
+        if (Ns > 1) {
+            int ti = 0; // (i k tws) mod N, built incrementally
+            const int dk = k * tws;
+#pragma unroll
+            for (int i = 1; i < RX; i++) {
+                ti += dk;
+                if (ti >= N) ti -= N;
+                const cf w = twl[ti];
+                x[i] = cf{x[i].x * w.x + x[i].y * (w.y * -s), x[i].y * w.x + x[i].x * (w.y * s)}; // * w (forward) or conj(w) (inverse)
+            }
+        }
+        if constexpr (RX == 2) dft2(x);
+        if constexpr (RX == 3) dft3(x, s);
+        if constexpr (RX == 4) dft4(x, s);
+        if constexpr (RX == 5) dft5(x, s);
+        if constexpr (RX == 8) dft8(x, s);
+        if constexpr (RX == 10) dft10(x, s);
+        cf* __restrict__ out = dst + row * N + (j - k) * RX + k;
+#pragma unroll
+        for (int i = 0; i < RX; i++) out[i * Ns] = x[i];
+    }
+}
+
+// row FFTs of the whole tile; on return `cur` points at the image that holds the result (natural order)
+__device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restrict__ twl, const GenFac& F, const bool inverse)
+{
+    const float s = inverse ? -1.f : 1.f;
+    int Ns = 1;
+    for (int q = 0; q < F.nf; q++) {
+        const int rx = F.radix[q];
+        switch (rx) {
+        case 2: gen_stage<2>(cur, other, twl, F.n, F.rows, Ns, s); break;
+        case 3: gen_stage<3>(cur, other, twl, F.n, F.rows, Ns, s); break;
+        case 4: gen_stage<4>(cur, other, twl, F.n, F.rows, Ns, s); break;
+        case 5: gen_stage<5>(cur, other, twl, F.n, F.rows, Ns, s); break;
+        case 8: gen_stage<8>(cur, other, twl, F.n, F.rows, Ns, s); break;
+        default: gen_stage<10>(cur, other, twl, F.n, F.rows, Ns, s); break;
+        }
+        __syncthreads();
+        cf* t_ = cur; cur = other; other = t_;
+        Ns *= rx;
+    }
+}
+
+// (float)(i1^2 + i2^2) * 9 / mindim^2 > 1: zeroHighFreq's test (src/multisliceSimulation.cu:241)
+__device__ __forceinline__ bool gen_outside(int i1, int i2, float md) { return ((float)(i1 * i1 + i2 * i2) * 9.f / (md * md)) > 1.f; }
+
+// EPT: elements a thread owns (element e = tid + 256 i of the R x N tile, row-major)
+template <int EPT, int PRE, int MID, int POST, bool STORE_T>
+__global__ __launch_bounds__(kGenThreads) void k_gpass(PassArgs A, GenFac F)
+{
+    extern __shared__ cf glds[];
+    const int N = F.n, R = F.rows, tid = threadIdx.x;
+    const int tile = R * N;
+    cf* cur = glds;
+    cf* other = glds + tile;
+    cf* twl = glds + 2 * tile;
+    const int nvirt = (int)gridDim.x, vb = (int)blockIdx.x;
+    int bg;
+    {   // XCD-aware remap (fft_lds.hip): workgroups of one XCD own consecutive row groups
+        const int q = nvirt >> 3, rem = nvirt & 7, xcd = vb & 7, k = vb >> 3;
+        bg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+    }
+    if (A.live_rows_only) {
+        const int L = A.band_L;
+        const int g_lo = L / R + 1, g_hi = (A.nrows - L) / R;
+        if (bg >= g_lo) bg = g_hi + (bg - g_lo);
+    }
+    const int row0 = bg * R;
+    const unsigned pin = A.pitch_in ? (unsigned)A.pitch_in : (unsigned)N;
+    const unsigned ldt = A.pitch_out ? (unsigned)A.pitch_out : (unsigned)A.nrows;
+    const size_t gbase = (size_t)row0 * pin;
+    const cf* __restrict__ in0 = A.in0 ? reinterpret_cast<const cf*>(A.in0) + gbase : nullptr;
+    const cf* __restrict__ in1 = A.in1 ? reinterpret_cast<const cf*>(A.in1) + gbase : nullptr;
+    const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
+    cf* const out0 = reinterpret_cast<cf*>(A.out) + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0);
+    if constexpr (PRE != XF_NONE || POST != XF_NONE) {
+        const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
+        for (int i = tid; i < N; i += kGenThreads) twl[i] = tw[i];
+    }
+    // this thread's elements: (row, column) of e = tid + 256 i; N >= 256, so a step wraps at most once
+    int er[EPT], ec[EPT];
+    {
+        int r = tid / N, c = tid - r * N;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            er[i] = r;
+            ec[i] = c;
+            c += kGenThreads;
+            if (c >= N) { c -= N; r++; }
+        }
+    }
+    auto valid = [&](int i) { return er[i] < R; };
+    auto load_tile = [&](const cf* __restrict__ src, cf* __restrict__ dstl, const bool band) {
+#pragma unroll
+        for (int i = 0; i < EPT; i++)
+            if (valid(i)) {
+                const bool dead = band && dead_index(iwc(ec[i], N), A.band);
+                dstl[er[i] * N + ec[i]] = dead ? cf{0.f, 0.f} : src[(unsigned)er[i] * pin + (unsigned)ec[i]];
+            }
+    };
+
+    float keep_f[(MID == MID_EXPIV_PAIR) ? EPT : 1]; // second slice's potential of a pair
+    if constexpr (MID == MID_GTABN) {
+        // sum over species in Fourier space (phaseGrating's species loop), then one inverse transform
+        cf acc[EPT];
+#pragma unroll
+        for (int i = 0; i < EPT; i++) acc[i] = cf{0.f, 0.f};
+        for (int z = 0; z < A.nspecies; z++) {
+            const size_t zo = (size_t)z * A.species_stride;
+            load_tile(in0 + zo, cur, false);
+            __syncthreads();
+            if constexpr (PRE != XF_NONE) gen_fft(cur, other, twl, F, PRE == XF_INV);
+#pragma unroll
+            for (int i = 0; i < EPT; i++)
+                if (valid(i)) {
+                    const float gv = gtab[zo + (unsigned)er[i] * pin + (unsigned)ec[i]];
+                    const cf v = cur[er[i] * N + ec[i]];
+                    acc[i].x += v.x * gv;
+                    acc[i].y += v.y * gv;
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; i++)
+            if (valid(i)) cur[er[i] * N + ec[i]] = acc[i];
+        __syncthreads();
+    } else {
+        if constexpr (MID == MID_ATOMS) {
+            // squareAtoms_d (src/crystalMaker.cu:73-123) from the (slice, species, row)-sorted records, as MID_ATOMS of
+            // fft_lds.hip: tile zeroed in LDS, ONE wave adds the bilinear weights with LDS float atomics in sorted order
+            const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs);
+            const int rlo = row0 > 0 ? row0 - 1 : 0;
+            const int rhi = (row0 + R + 1 < A.nrows) ? row0 + R + 1 : A.nrows;
+            int plo[2] = {0, 0}, phi[2] = {0, 0};
+#pragma unroll
+            for (int comp = 0; comp < 2; comp++) {
+                const int q = (comp ? A.q1 : A.q0) < 0 ? -1 : (comp ? A.q1 : A.q0) + (int)blockIdx.y;
+                if (q >= 0) {
+                    const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
+                    plo[comp] = rs[rlo];
+                    phi[comp] = rs[rhi];
+                }
+            }
+            if (phi[0] - plo[0] + phi[1] - plo[1] == 0) { // workgroup-uniform: the spectrum of an empty row group is zero
+                if constexpr (STORE_T) {
+                    for (int e = tid; e < tile; e += kGenThreads) (out0 + row0)[(unsigned)(e / R) * ldt + (unsigned)(e % R)] = cf{0.f, 0.f};
+                }
+                return;
+            }
+            for (int e = tid; e < tile; e += kGenThreads) cur[e] = cf{0.f, 0.f};
+            __syncthreads();
+            if (tid < 64) {
+                float* ldsf = reinterpret_cast<float*>(cur);
+#pragma unroll 1
+                for (int comp = 0; comp < 2; comp++) {
+#pragma unroll 1
+                    for (int base = plo[comp]; base < phi[comp]; base += 64) {
+                        const int i = base + tid;
+                        if (i < phi[comp]) {
+                            const AtomRec ar = recs[i];
+                            const float a1 = fabsf(ar.r1), a2 = fabsf(ar.r2);
+                            const int s1 = ar.r1 < 0.f ? -1 : 1, s2 = ar.r2 < 0.f ? -1 : 1;
+#pragma unroll
+                            for (int px = 0; px < 4; px++) {
+                                // pixel order of the reference: (i1,i2), (i1,i2+s2), (i1+s1,i2+s2), (i1+s1,i2)
+                                const int c = ar.i1 + ((px == 2 || px == 3) ? s1 : 0);
+                                const int rr = ar.i2 + ((px == 1 || px == 2) ? s2 : 0) - row0;
+                                const float wgt = ((px == 2 || px == 3) ? a1 : (1 - a1)) * ((px == 1 || px == 2) ? a2 : (1 - a2)) * ar.occ;
+                                if (rr >= 0 && rr < R && c >= 0 && c < N) atomicAdd(&ldsf[2 * (rr * N + c) + comp], wgt);
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            load_tile(in0, cur, (A.skip_dead_loads & 1) != 0);
+        }
+        cf keep_b[(MID == MID_MULPSI) ? EPT : 1]; // second operand of the product, transformed, in registers
+        if constexpr (MID == MID_MULPSI) {
+            // the second operand goes through the tile images first and waits in registers
+            cf* c2 = other; // `cur` holds the first operand
+            cf* o2 = twl + N; // third image behind the twiddle table
+            load_tile(in1, c2, (A.skip_dead_loads & 2) != 0);
+            __syncthreads();
+            if constexpr (PRE != XF_NONE) {
+                // ping-pong between `other` and the third image; `cur` is not touched
+                gen_fft(c2, o2, twl, F, PRE == XF_INV);
+            }
+#pragma unroll
+            for (int i = 0; i < EPT; i++)
+                if (valid(i)) keep_b[i] = c2[er[i] * N + ec[i]];
+        }
+        __syncthreads();
+        if constexpr (PRE != XF_NONE) gen_fft(cur, other, twl, F, PRE == XF_INV);
+        // ---- point-wise operation on this thread's elements
+        const float md = (float)A.mindim;
+#pragma unroll
+        for (int i = 0; i < EPT; i++)
+            if (valid(i)) {
+                cf v = cur[er[i] * N + ec[i]];
+                const int grow = row0 + er[i];
+                if constexpr (MID == MID_SCALE) v = v * A.scale;
+                if constexpr (MID == MID_GTAB) v = v * gtab[(unsigned)er[i] * pin + (unsigned)ec[i]];
+                if constexpr (MID == MID_MASK) v = gen_outside(iwc(ec[i], N), iwc(grow, A.nrows), md) ? cf{0.f, 0.f} : v * A.scale;
+                if constexpr (MID == MID_PTAB) {
+                    const cf pr = reinterpret_cast<const cf*>(A.prow)[grow], pc = reinterpret_cast<const cf*>(A.pcol)[ec[i]];
+                    v = gen_outside(iwc(ec[i], N), iwc(grow, A.nrows), md) ? cf{0.f, 0.f} : cmul3(v, cmul3(pr, pc));
+                }
+                if constexpr (MID == MID_MULPSI) v = cmul3(v, keep_b[i]); // f0 = t, f1 = psi
+                if constexpr (MID == MID_EXPIV_PAIR) {
+                    keep_f[i] = v.y;
+                    float sn, cs;
+                    const float e = (A.scale == 0.f) ? 1.f : __expf(-(v.x * A.scale));
+                    if (fabsf(v.x) <= kSincosFast) sincos_cw(v.x, sn, cs);
+                    else sincos_wide(v.x, sn, cs);
+                    v = cf{e * cs, e * sn};
+                }
+                cur[er[i] * N + ec[i]] = v;
+            }
+        __syncthreads();
+    }
+    auto store_tile = [&](cf* outp) {
+        if constexpr (!STORE_T) {
+            const unsigned pout = A.pitch_out ? (unsigned)A.pitch_out : (unsigned)N;
+            cf* __restrict__ on = outp + (size_t)row0 * pout;
+#pragma unroll
+            for (int i = 0; i < EPT; i++)
+                if (valid(i)) on[(unsigned)er[i] * pout + (unsigned)ec[i]] = cur[er[i] * N + ec[i]];
+        } else {
+            // transposed grid: N rows of length ldt; consecutive threads write the R consecutive elements of one output row
+            cf* __restrict__ dst = outp + row0;
+            for (int e = tid; e < tile; e += kGenThreads) {
+                const int c = e / R, rr = e - c * R;
+                if (A.skip_dead_stores && dead_index(iwc(c, N), A.band)) continue;
+                dst[(unsigned)c * ldt + (unsigned)rr] = cur[rr * N + c];
+            }
+        }
+    };
+    if constexpr (POST != XF_NONE) gen_fft(cur, other, twl, F, POST == XF_INV);
+    store_tile(out0);
+    if constexpr (MID == MID_EXPIV_PAIR) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < EPT; i++)
+            if (valid(i)) {
+                const float v = keep_f[i];
+                float sn, cs;
+                const float e = (A.scale == 0.f) ? 1.f : __expf(-(v * A.scale));
+                if (fabsf(v) <= kSincosFast) sincos_cw(v, sn, cs);
+                else sincos_wide(v, sn, cs);
+                cur[er[i] * N + ec[i]] = cf{e * cs, e * sn};
+            }
+        __syncthreads();
+        if constexpr (POST != XF_NONE) gen_fft(cur, other, twl, F, POST == XF_INV);
+        store_tile(reinterpret_cast<cf*>(A.out2));
+    }
+}
+
+#undef float2
+#undef make_float2
+
+bool factorize(int n, GenFac& f)
+{
+    f.n = n;
+    f.nf = 0;
+    int m = n;
+    // large radices first: fewer stages (each stage is one trip of the tile through LDS)
+    const int cand[6] = {10, 8, 5, 4, 3, 2};
+    for (int ci = 0; ci < 6; ci++)
+        while (m % cand[ci] == 0 && m > 1) {
+            if (f.nf == 8) return false;
+            f.radix[f.nf++] = cand[ci];
+            m /= cand[ci];
+        }
+    return m == 1;
+}
+
+int gen_rows(int n) { return n > 512 ? 4 : 8; }
+
+template <int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaunch(const PassArgs& a, const GenFac& f, hipStream_t st)
+{
+    static std::atomic<unsigned long long> attr_set{0};
+    auto kern = k_gpass<EPT, PRE, MID, POST, ST>;
+    // two images of the tile + the twiddle table (+ a third image for the second operand of a product)
+    const size_t lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * ((MID == MID_MULPSI) ? 3 : 2) + (size_t)f.n) + 64;
+    int dev = 0;
+    {
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+    }
+    if (dev < 0 || dev >= 64 || !((attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (a.nrows % f.rows != 0) return hipErrorInvalidValue;
+    int groups = a.nrows / f.rows;
+    PassArgs w = a;
+    if (a.live_rows_only) {
+        if (a.band <= 0) return hipErrorInvalidValue;
+        const int L = a.band_L;
+        const int g_lo = L / f.rows + 1, g_hi = (a.nrows - L) / f.rows;
+        if (g_hi > g_lo) groups = g_lo + (a.nrows / f.rows - g_hi);
+        else w.live_rows_only = 0;
+    }
+    const int ny = (MID == MID_ATOMS) ? (a.nspecies > 0 ? a.nspecies : 1) : 1;
+    if (a.ev_start && a.ev_stop) {
+        w.ev_start = w.ev_stop = nullptr;
+        hipExtLaunchKernelGGL(kern, dim3(groups, ny), dim3(kGenThreads), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w, f);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(kern, dim3(groups, ny), dim3(kGenThreads), lds_bytes, st, w, f);
+    return hipGetLastError();
+}
+
+template <int EPT> hipError_t gdispatch(int pre, int mid, int post, bool st_t, const PassArgs& a, const GenFac& f, hipStream_t st)
+{
+#define CASE(P_, M_, Q_, S_) if (pre == P_ && mid == M_ && post == Q_ && st_t == S_) return glaunch<EPT, P_, M_, Q_, S_>(a, f, st);
+    CASE(XF_NONE, MID_NONE, XF_NONE, false)
+    CASE(XF_NONE, MID_NONE, XF_NONE, true)
+    CASE(XF_NONE, MID_SCALE, XF_NONE, true)
+    CASE(XF_FWD, MID_NONE, XF_NONE, false)
+    CASE(XF_INV, MID_NONE, XF_NONE, false)
+    CASE(XF_INV, MID_SCALE, XF_NONE, false)
+    CASE(XF_FWD, MID_NONE, XF_NONE, true)
+    CASE(XF_INV, MID_NONE, XF_NONE, true)
+    CASE(XF_FWD, MID_ATOMS, XF_NONE, true)
+    CASE(XF_INV, MID_EXPIV_PAIR, XF_FWD, true)
+    CASE(XF_FWD, MID_GTAB, XF_INV, true)
+    CASE(XF_FWD, MID_GTABN, XF_INV, true)
+    CASE(XF_FWD, MID_MASK, XF_INV, true)
+    CASE(XF_INV, MID_MULPSI, XF_FWD, true)
+    CASE(XF_NONE, MID_MULPSI, XF_FWD, true)
+    CASE(XF_FWD, MID_PTAB, XF_INV, true)
+#undef CASE
+    return hipErrorInvalidValue;
+}
+
+} // namespace
+
+bool gen_pass_supported_len(int n)
+{
+    if (n < 256 || n > 2048) return false;
+    if ((n & (n - 1)) == 0) return false; // powers of two have kernels of their own
+    GenFac f;
+    return factorize(n, f);
+}
+int gen_pass_rows(int n) { return gen_rows(n); }
+
+void gen_pass_twiddles(int n, float* tw)
+{
+    const double w = -2.0 * 3.14159265358979323846 / (double)n;
+    for (int k = 0; k < n; k++) {
+        tw[2 * k] = (float)std::cos(w * (double)k);
+        tw[2 * k + 1] = (float)std::sin(w * (double)k);
+    }
+}
+
+hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
+{
+    GenFac f;
+    if (!gen_pass_supported_len(n) || !factorize(n, f)) return hipErrorInvalidValue;
+    f.rows = gen_rows(n);
+    const int ept = (f.rows * n + kGenThreads - 1) / kGenThreads;
+    if (ept <= 16) return gdispatch<16>(pre, mid, post, st_t, a, f, st);
+    if (ept <= 32) return gdispatch<32>(pre, mid, post, st_t, a, f, st);
+    return hipErrorInvalidValue;
+}
+
+} // namespace fdes

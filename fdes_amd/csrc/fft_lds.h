@@ -83,7 +83,8 @@ struct PassArgs {
     void* ev_stop = nullptr;
 };
 
-// Row lengths the kernels are instantiated for.
+// Row lengths the register-resident kernels are instantiated for (powers of two, 256 ... 4096); lds_pass() also takes
+// the lengths of gen_pass_supported_len().
 bool lds_fft_supported_len(int n);
 // rows per workgroup for row length n and wg threads per workgroup (512: one workgroup per CU; 256: two)
 int lds_fft_rows_per_block(int n, int wg);
@@ -93,6 +94,13 @@ void lds_fft_twiddles(int n, float* tw0, float* tw1);
 // one-wave-per-row passes (fft_wave.hip)
 bool wave_pass_supported_len(int n);
 hipError_t wave_pass(int n, int pre, int mid, int post, bool store_transposed, const PassArgs& a, hipStream_t st);
+
+// LDS-resident mixed-radix passes for row lengths 2^a 3^b 5^c in [256, 2048] that are not powers of two (fft_gen.hip);
+// their twiddle table is the n roots of unity W_n^k (float2 as 2 floats)
+bool gen_pass_supported_len(int n);
+int gen_pass_rows(int n);
+void gen_pass_twiddles(int n, float* tw);
+hipError_t gen_pass(int n, int pre, int mid, int post, bool store_transposed, const PassArgs& a, hipStream_t st);
 
 // Launch one pass over all rows. n = row length, kinds select the template instantiation.
 hipError_t lds_pass(int n, int pre, int mid, int post, bool store_transposed, const PassArgs& a, hipStream_t st);

@@ -780,6 +780,7 @@ template <int N> hipError_t dispatch_wg(int pre, int mid, int post, bool st_t, c
 bool lds_fft_supported_len(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
 int lds_fft_rows_per_block(int n, int wg)
 {
+    if (gen_pass_supported_len(n)) return gen_pass_rows(n);
     if (wg == 64 || wg == 65) return wave_pass_supported_len(n) ? 4 : 256 * 2 * 16 / n;
     return wg == 1 ? 4 : (wg == 256 ? 256 * 2 : 512 * 2) * 16 / n;
 }
@@ -810,6 +811,7 @@ hipError_t lds_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
         a.band_L = live_limit(a.band);
         if (a.band_L != n / 3) a.skip_dead_loads = 0; // the kernel's column classes assume the band of a square grid
     }
+    if (gen_pass_supported_len(n)) return gen_pass(n, pre, mid, post, st_t, a, st);
     if (a.wg == 64 || a.wg == 65) {
         if (wave_pass_supported_len(n)) return wave_pass(n, pre, mid, post, st_t, a, st);
         a.wg = 256; // shorter rows: two rows per thread

@@ -35,6 +35,9 @@ hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, const float* oc
 hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key, const BinGeom& g,
                         float imPot, int blocks, hipStream_t st);
 
+// deterministic deposit from the sorted records (needs geom_bin_atoms(..., with_rows = true)): component x <- segment
+// key0, component y <- segment key1 (-1: none), or with_impot: y = imPot * x; overwrites V (no clearing needed)
+hipError_t geom_deposit_tile(float2* V, const AtomBins& b, int key0, int key1, bool with_impot, float imPot, const BinGeom& g, hipStream_t st);
 hipError_t geom_deposit_pair(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key0, int key1, const BinGeom& g,
                              int blocks, hipStream_t st);
 

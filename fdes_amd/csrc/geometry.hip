@@ -17,6 +17,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "geometry.h"
+
+#include <atomic>
 #include "rng.h"
 
 namespace fdes {
@@ -168,6 +170,56 @@ __global__ void k_deposit_pair(float2* __restrict__ V, const float* __restrict__
     }
 }
 
+// Deterministic deposit ("sorted scatter option"): one workgroup owns R rows of the grid.  The rows are zeroed
+// in LDS, ONE wave adds the bilinear weights of the atoms whose footprint touches them - 64 at a time, in the sorted
+// (slice, species, row) order of the records - with LDS float atomics, then the tile overwrites the grid rows with
+// plain stores.  Instructions of one wave reach the LDS in program order and colliding lanes of one instruction are
+// serialised in a fixed order, so the sums do not depend on timing (k_deposit / k_deposit_pair: global float atomics
+// as the reference's squareAtoms_d, src/crystalMaker.cu:100-119, whose last bits depend on arrival order).
+// q0 -> component x, q1 -> component y (-1: none); with_impot: y = imPot * (the x deposit) instead.
+__global__ void k_deposit_tile(float2* __restrict__ V, const AtomRec* __restrict__ recs, const int* __restrict__ rowstart, int q0, int q1,
+                               int with_impot, float imPot, int m1, int m2, int R)
+{
+    extern __shared__ float2 dtile[];
+    const int tid = threadIdx.x, row0 = (int)blockIdx.x * R;
+    const int nr = (row0 + R <= m2) ? R : m2 - row0;
+    for (int e = tid; e < nr * m1; e += blockDim.x) dtile[e] = make_float2(0.f, 0.f);
+    __syncthreads();
+    if (tid < 64) {
+        float* tf = reinterpret_cast<float*>(dtile);
+        const int rlo = row0 > 0 ? row0 - 1 : 0;
+        const int rhi = (row0 + nr + 1 < m2) ? row0 + nr + 1 : m2;
+        for (int comp = 0; comp < (with_impot ? 1 : 2); comp++) {
+            const int q = comp ? q1 : q0;
+            if (q < 0) continue;
+            const int* __restrict__ rs = rowstart + (size_t)q * (size_t)(m2 + 1);
+            const int plo = rs[rlo], phi = rs[rhi];
+            for (int base = plo; base < phi; base += 64) {
+                const int i = base + tid;
+                if (i < phi) {
+                    const AtomRec ar = recs[i];
+                    const float a1 = fabsf(ar.r1), a2 = fabsf(ar.r2);
+                    const int s1 = ar.r1 < 0.f ? -1 : 1, s2 = ar.r2 < 0.f ? -1 : 1;
+#pragma unroll
+                    for (int px = 0; px < 4; px++) {
+                        // pixel order of the reference: (i1,i2), (i1,i2+s2), (i1+s1,i2+s2), (i1+s1,i2)
+                        const int c = ar.i1 + ((px == 2 || px == 3) ? s1 : 0);
+                        const int rr = ar.i2 + ((px == 1 || px == 2) ? s2 : 0) - row0;
+                        const float w = ((px == 2 || px == 3) ? a1 : (1 - a1)) * ((px == 1 || px == 2) ? a2 : (1 - a2)) * ar.occ;
+                        if (rr >= 0 && rr < nr && c >= 0 && c < m1) {
+                            atomicAdd(&tf[2 * (rr * m1 + c) + comp], w);
+                            if (with_impot) atomicAdd(&tf[2 * (rr * m1 + c) + 1], w * imPot);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float2* __restrict__ out = V + (size_t)row0 * m1;
+    for (int e = tid; e < nr * m1; e += blockDim.x) out[e] = dtile[e];
+}
+
 static inline int blocks_for(int n, int bs, int cap) { int b = (n + bs - 1) / bs; if (b < 1) b = 1; return b > cap ? cap : b; }
 
 hipError_t geom_srot(float* xyz, int nAt, int ax, int ay, float c, float s, hipStream_t st)
@@ -228,6 +280,29 @@ hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const Ato
                         float imPot, int blocks, hipStream_t st)
 {
     hipLaunchKernelGGL(k_deposit, dim3(blocks), dim3(256), 0, st, V, xyz, occ, b.order, b.seg, key, g, imPot);
+    return hipGetLastError();
+}
+
+hipError_t geom_deposit_tile(float2* V, const AtomBins& b, int key0, int key1, bool with_impot, float imPot, const BinGeom& g, hipStream_t st)
+{
+    if (!b.rowstart || !b.recs_sorted) return hipErrorInvalidValue;
+    int R = 8192 / (g.m1 > 0 ? g.m1 : 1); // tile of at most 64 KiB (one float2 per pixel), 1 ... 8 rows
+    R = R < 1 ? 1 : (R > 8 ? 8 : R);
+    const size_t lds = sizeof(float2) * (size_t)R * (size_t)g.m1;
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> attr_set{0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64 || !((attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_deposit_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) attr_set.fetch_or(1ull << dev, std::memory_order_release);
+        }
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(k_deposit_tile, dim3((g.m2 + R - 1) / R), dim3(256), lds, st, V, b.recs_sorted, b.rowstart, key0, key1, with_impot ? 1 : 0,
+                       imPot, g.m1, g.m2, R);
     return hipGetLastError();
 }
 

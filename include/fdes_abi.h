@@ -199,7 +199,8 @@ int64_t fdes_plan_slices_done(const fdes_plan* plan);
 int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
 
 /* Engine options (before fdes_plan_create).  Unknown keys -> FDES_EINVAL.  (Test / bench-only keys: fdes_abi_test.h.)
- *   "fft"        0 = auto, 1 = rocFFT, 2 = hand-written LDS FFT kernels (power-of-two grids)
+ *   "fft"        0 = auto, 1 = rocFFT, 2 = hand-written LDS FFT kernels (grid lengths 256 ... 4096 that are powers of two,
+ *                or 2^a 3^b 5^c up to 2048: the 320-, 800- and 1000-point grids of the reference's examples)
  *   "graph"      1 = replay the slice loop from a hipGraph
  *   "seed"       frozen-phonon seed (reference: 1, src/crystalMaker.cu:292)
  *   "band_skip"  1 (default): rows / columns that the radial 2/3 band limit zeroes whatever the other index is are
@@ -208,12 +209,17 @@ int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
  *                (2 passes instead of 5-6); 0: every slice goes through the full sequence like the reference
  *   "lanes"      1..4 configurations in flight at once in the fused slice loop (default 2): run_config calls are
  *                dealt round-robin to lanes, partial intensity sums are folded in end_measurement
- *   "pass_threads"  0 auto, 256 or 512 threads per LDS-pass workgroup
+ *   "pass_threads"  0 auto; 256 or 512 threads x two rows per thread; 1: one row per thread, four rows per workgroup;
+ *                64: one wave per row (2048- and 4096-point rows); 65: the same as a software pipeline
  *   "split"      -1 (default): a plan with one lane (single-image jobs; a plan never has more lanes than the job has
  *                configurations) and at least 2^20 pixels runs the potential / transmission passes of its slice loop on a second stream, one
  *                slice pair ahead of the wave's passes; 0 never, 1 always
  *   "pitch_pad"  -1 (default: 32 for 2048-point rows, 64 from 4096 on) elements of padding per row of the slice loop's grids
  *   "walk"       1 (default) .. 8: launch every pass in that many parts
+ *   "deterministic"  1 (default): the deposit of the rocFFT slice loop and of the potential output adds the atoms in sorted
+ *                order through LDS (bit-reproducible, like the fused loop); 0: global float atomics as the reference's
+ *                squareAtoms_d (src/crystalMaker.cu:100-119)
+ *   "stagger"    0 (default) .. 1024: one-wave-per-row passes start the waves of a CU that many x 64 cycles apart
  *   "peer_copy"  1 (default): fdes_plan_accumulate_from moves a partial sum between GPUs by a peer copy and falls back
  *                to host staging when the runtime refuses it; 0: always stage through host memory                 */
 int fdes_set_option(fdes_ctx* ctx, const char* key, int64_t value);

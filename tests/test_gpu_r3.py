@@ -133,3 +133,66 @@ def test_wave_passes_equal_lanes_graph_and_empty_slices(oracle, threads):
     e = relerr(img, r64)
     print(f"[parity] wave passes, driver 2048^2 frPh=3 with empty slices: E = {e:.3e}")
     assert e <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mixed-radix LDS-resident passes (fft_gen.hip): the grid sizes of the reference's own examples (320, 800, 1000)
+# ------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(320, 320), (800, 800), (1000, 1000), (1000, 512), (640, 960), (1280, 1500), (2000, 1920)])
+def test_mixed_radix_fft_against_numpy(engine, shape):
+    """Row FFTs of length 2^a 3^b 5^c (Stockham stages of radix 10, 8, 5, 4, 3, 2 in LDS) as a 2-D transform against
+    numpy, also paired with a power-of-two length (cufftPlan2d serves any size, src/paramStructure.cu:676-679)."""
+    rng = np.random.default_rng(13)
+    f = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    for inv in (False, True):
+        out, used = engine.fft2(f, inv, backend=2)
+        assert used == 2
+        ref = np.fft.ifft2(f.astype(np.complex128)) * f.size if inv else np.fft.fft2(f.astype(np.complex128))
+        e = relerr(out, ref)
+        print(f"[parity] mixed-radix fft {shape} inv={inv}: rel L2 {e:.3e}")
+        assert e < 6e-7
+
+
+@pytest.mark.parametrize("m,nz", [(320, 1), (320, 2), (800, 1), (1000, 2)])
+def test_mixed_radix_slice_loop(oracle, m, nz):
+    """The fused slice loop on 320 / 800 / 1000-point grids (before round 3: rocFFT + point-wise kernels, 24 launches per
+    slice): exit wave after an odd number of slices and the potential of both members of a pair against the float64
+    oracle, one and two species, with and without the empty-slice short cut."""
+    hp, at = S.case_tiny(m=m, m3=5, nz=nz, nat=300, tilt=True, seed=51 + nz)
+    fdes_amd.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    ref = oracle.wave(q, at, 0, 0, prec="f64")
+    r32 = oracle.wave(q, at, 0, 0, prec="f32")
+    for skip in (0, 1):
+        eng = fdes_amd.Engine(0, skip_empty=skip)
+        pl = eng.plan(hp, at)
+        assert pl.fft_backend() == 2
+        psi = pl.tap_wave(0, 0)
+        check(psi, ref, r32, 1e-5, f"mixed-radix slice loop {m}^2 nz={nz} skip_empty={skip}")
+        if skip == 0:
+            xyz = oracle.config_coords(q, at, 0, -1)
+            for s in (2, 3):
+                V = pl.tap_potential(0, 0, s)
+                check(V, oracle.phase_grating(q, at, xyz, s, "f64"), None, 1e-5, f"mixed-radix potential s={s} {m}^2 nz={nz}")
+        pl.close()
+        eng.close()
+
+
+@pytest.mark.parametrize("kw", [dict(m=320, m3=6, nz=2, frPh=3, nat=200, tilt=True), dict(m=800, m3=4, nz=2, mode=2, nat=150),
+                                dict(m=1000, m3=4, nz=1, mode=1, beam_tilt=True, nat=150), dict(m=640, rect=True, m3=3, nz=2, nat=100)])
+def test_mixed_radix_driver_images(oracle, kw):
+    """Whole driver (lanes, graph replay, detector chain) on non-power-of-two grids: images against the float64 oracle
+    resp. the float32 oracle for frozen-phonon runs; the same through rocFFT for comparison."""
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0)
+    img = eng.build_measurements(hp, at)["image"]
+    eng.close()
+    eng = fdes_amd.Engine(0, fft=1)
+    img_r = eng.build_measurements(hp, at)["image"]
+    eng.close()
+    ref = oracle.build_measurements(hp, at, prec="f64" if kw.get("frPh", 0) == 0 else "f32")["image"]
+    e, er = relerr(img, ref), relerr(img_r, ref)
+    print(f"[parity] mixed-radix driver {kw}: E(fused) = {e:.3e}, E(rocFFT path) = {er:.3e}")
+    assert e <= 1e-5
