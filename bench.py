@@ -176,7 +176,8 @@ def main():
             while 9 * L * L > m * m:
                 L -= 1
             live = min(m, 2 * L + 1)
-            kname = f"k_pass<{m}, INV, MULPSI, FWD, transposed> (P5 of 6 passes/slice), {live} of {m} kx columns live"
+            kname = (f"{'k_wpass' if m == 2048 else 'k_pass'}<{m}, INV, MULPSI, FWD, transposed> (P5 of 6 passes/slice), "
+                     f"{live} of {m} kx columns live")
             alg_bytes = 24.0 * m * live
         else:
             # one rocFFT 2-D C2C = 2 passes x (8 B read + 8 B write) per pixel ("FFT pass 16 B/px")
@@ -279,18 +280,20 @@ def _blob_hash(path):
 
 def pmc_traffic(m):
     """HBM bytes per launch of the probed kernel (P5) from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
-    gfx950 correction + WRITE_SIZE; profiles/r02_pmc.json, tools/profile_round.sh).  PMC counters cannot be collected from
-    inside this process, so the number is the offline measurement of the same kernel: the file records the git blob hash
-    of the kernel source it was measured on, and a different hash here returns (None, True) - stale - instead of a
-    number that may belong to another build.  (None, False) for sizes that were not profiled."""
+    gfx950 correction + WRITE_SIZE; profiles/r03_pmc.json, tools/profile_round.sh).  PMC counters cannot be collected from
+    inside this process, so the number is the offline measurement of the same kernel: the file records the git blob hashes
+    of the sources that decide what a pass moves (kernels, shared arithmetic, pass arguments, the engine), and any
+    difference here returns (None, True) - stale - instead of a number that may belong to another build.  (None, False)
+    for sizes that were not profiled."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-        src = "fdes_amd/csrc/fft_lds.hip"
-        if d.get("source_hash", {}).get(src) != _blob_hash(os.path.join(ROOT, src)):
-            return None, True
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+        for src, h in d.get("source_hash", {}).items():
+            if h != _blob_hash(os.path.join(ROOT, src)):
+                return None, True
         for wl in d["workloads"].values():
             for k, v in wl.items():
-                if k.startswith(f"k_pass<{m},") and k.endswith("2, 5, 1, true>") and "hbm_bytes_per_launch_corrected" in v:
+                # P5: (PRE, MID, POST, transposed) = (2, 5, 1, true) of whichever kernel family serves this row length
+                if k.startswith((f"k_pass<{m},", f"k_wpass<{m},")) and ", 2, 5, 1, true" in k and "hbm_bytes_per_launch_corrected" in v:
                     return v["hbm_bytes_per_launch_corrected"], False
     except Exception:
         pass

@@ -52,6 +52,7 @@ struct fdes_ctx {
     int split = -1;       // potential / transmission passes (P1'..P4) on a stream of their own, one slice pair ahead of the
                           // wave's passes (P5, P6): concurrency inside ONE configuration; -1 auto, 0 off, 1 on (issued
                           // directly, never captured into a graph)
+    int batch = -1;       // slice pairs per launch of the potential chain of a one-lane plan: -1 auto (by grid size), 0 / 1 off, 2 ... 8
     int stagger = 0;      // one-wave-per-row passes: start delay between the waves of a CU, in units of 64 cycles (0: none)
     int walk = 1;         // every pass is launched in this many parts (2: a part takes half of the workgroup slots, two lanes' passes share every CU)
     int pitch_pad = -1;   // elements added to every row of the fused loop's grids; -1 auto: 32 for 2048-point rows, 64 from 4096 on
@@ -153,6 +154,12 @@ struct fdes_plan {
     float2* Eb[2] = {nullptr, nullptr};  // band-limited transmission spectra of the pair's two slices (split: two buffers)
     hipEvent_t evE[2] = {nullptr, nullptr}, evP5[2] = {nullptr, nullptr}, evFork = nullptr, evJoin = nullptr;
     bool p5_seen[2] = {false, false};
+    // batched potential chain (one-lane plans up to 2^20 pixels): `nb` slice pairs per launch of the potential /
+    // transmission passes (grid.z), their band-limited transmission spectra in two sets of 2 nb grids that the wave chain
+    // consumes one batch behind
+    int nb = 1;
+    float2 *bA = nullptr, *bB = nullptr, *bCC = nullptr, *bE[2] = {nullptr, nullptr};
+    hipEvent_t evReady[2] = {nullptr, nullptr}, evDone[2] = {nullptr, nullptr};
     float2* peer_stage = nullptr;   // landing buffer for another GPU's partial sum (fdes_plan_accumulate_from)
     bool peer_host_only = false;    // the peer copy was refused once: partial sums are staged through host memory (option "peer_copy" 0 forces it)
     std::vector<float2> peer_host;
@@ -425,63 +432,45 @@ int propagator_pow(fdes_plan* pl, int n, float2** out)
     return FDES_OK;
 }
 
-// one slice of the fused loop; *consumed = slices advanced (a run of empty slices is one Fresnel step with P^n)
-int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
+// a run of slices without atoms, starting at s: V = 0, t = BL(1) = 1; psi <- F^-1[P^n F[psi]] as one Fresnel step.
+// PSIH is [y][kx]: a transposing copy gives the y-pass its rows, then the usual propagator pass.
+int fused_empty_run(fdes_plan* pl, int s, int nslices, int* consumed)
 {
-    *consumed = 1;
     fdes_ctx* c = pl->ctx;
     const int m1 = pl->p.m1, m2 = pl->p.m2;
-    // 2/3 band limit: rows/columns whose own frequency index already fails 9 i^2 <= mindim^2 are exact zeros after
-    // P4 (mask) and P6 (masked propagator): P4/P6 run only their live row groups, P3/P5 do not store the rows those
-    // never read, P5 does not load the columns they never write (pre-zeroed at plan creation).
     const int md = m1 < m2 ? m1 : m2, band = md * md;
-    const int bs = (owner_ctx(pl)->band_skip && m1 == m2) ? 1 : 0; // the column classes of the passes assume the band of a square grid
+    const int bs = (owner_ctx(pl)->band_skip && m1 == m2) ? 1 : 0;
     auto empty = [&](int q) { return q >= pl->p.m3 || pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ]; };
-    const bool have_seg = !pl->seg_h.empty();
-    if (have_seg && empty(s)) {
-        // no atom in this slice: V = 0, t = BL(1) = 1; psi <- F^-1[P F[psi]].  PSIH is [y][kx]: a transposing
-        // copy gives the y-pass its rows, then the usual propagator pass.
-        PassArgs a5 = pass_x(pl);
-        a5.in0 = pl->PSIH; a5.out = pl->F;
-        a5.scale = (float)m1; // P5 hands m1 * FFT_x(t psi) to P6 (unnormalised x round trip); exact power of two
-        // (an incoming wave that is not band-limited in kx needs no special case here: the dead kx rows this copy drops are
-        // zeroed by the masked propagator whatever they held)
-        a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
-        HIPCHK(c, lds_pass(m1, XF_NONE, MID_SCALE, XF_NONE, true, a5, c->stream));
-        int run = 1;
-        while (s + run < nslices && empty(s + run)) run++;
-        float2* ptab = pl->PT;
-        if (run > 1) RC(propagator_pow(pl, run, &ptab));
-        PassArgs a6 = pass_y(pl);
-        a6.in0 = pl->F; a6.prow = ptab; a6.pcol = ptab + m1; a6.mindim = md; a6.out = pl->PSIH;
-        a6.band = band; a6.live_rows_only = bs;
-        HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
-        pl->slices_skipped += run;
-        *consumed = run;
-        return FDES_OK;
-    }
-    // the pair's potential and both transmission functions are built at the pair's first non-empty slice:
-    // C <- F_x[t_s0], C2 <- F_x[t_(s0+1)] from one read and one inverse transform of W = V_s0 + i V_(s0+1)
-    if ((s & 1) == 0 || (have_seg && empty(s - 1))) {
-        RC(fused_potential_pair(pl, s & ~1));
-        PassArgs a3 = pass_x(pl);
-        a3.in0 = pl->B; a3.out = pl->C; a3.out2 = pl->C2; a3.scale = pl->p.imPot;
-        a3.band = band; a3.skip_dead_stores = bs;
-        HIPCHK(c, lds_pass(m1, XF_INV, MID_EXPIV_PAIR, XF_FWD, true, a3, vstream(pl)));
-    }
-    const bool split = pl->split && !pl->tap_mode;
-    const int ei = s & 1;
-    PassArgs a4 = pass_y(pl);
-    a4.in0 = (s & 1) ? pl->C2 : pl->C; a4.out = pl->Eb[ei]; a4.scale = 1.f / ((float)pl->m12); a4.mindim = md;
-    a4.band = band; a4.live_rows_only = bs;
-    if (split && pl->p5_seen[ei]) HIPCHK(c, hipStreamWaitEvent(pl->vs, pl->evP5[ei], 0)); // the wave chain has consumed this buffer
-    HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, vstream(pl)));
-    if (split) {
-        HIPCHK(c, hipEventRecord(pl->evE[ei], pl->vs));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, pl->evE[ei], 0));
-    }
     PassArgs a5 = pass_x(pl);
-    a5.in0 = pl->Eb[ei]; a5.in1 = pl->PSIH; a5.out = pl->F;
+    a5.in0 = pl->PSIH; a5.out = pl->F;
+    a5.scale = (float)m1; // P5 hands m1 * FFT_x(t psi) to P6 (unnormalised x round trip); exact power of two
+    // (an incoming wave that is not band-limited in kx needs no special case here: the dead kx rows this copy drops are
+    // zeroed by the masked propagator whatever they held)
+    a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
+    HIPCHK(c, lds_pass(m1, XF_NONE, MID_SCALE, XF_NONE, true, a5, c->stream));
+    int run = 1;
+    while (s + run < nslices && empty(s + run)) run++;
+    float2* ptab = pl->PT;
+    if (run > 1) RC(propagator_pow(pl, run, &ptab));
+    PassArgs a6 = pass_y(pl);
+    a6.in0 = pl->F; a6.prow = ptab; a6.pcol = ptab + m1; a6.mindim = md; a6.out = pl->PSIH;
+    a6.band = band; a6.live_rows_only = bs;
+    HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
+    pl->slices_skipped += run;
+    *consumed = run;
+    return FDES_OK;
+}
+
+// the wave's two passes of slice s: P5 (t psi from the band-limited transmission spectrum E and psi-hat) and P6
+// (Fresnel propagator); ei >= 0: the split loop's "E consumed" event of that buffer is recorded behind P5
+int fused_wave_step(fdes_plan* pl, int s, const float2* E, int ei)
+{
+    fdes_ctx* c = pl->ctx;
+    const int m1 = pl->p.m1, m2 = pl->p.m2;
+    const int md = m1 < m2 ? m1 : m2, band = md * md;
+    const int bs = (owner_ctx(pl)->band_skip && m1 == m2) ? 1 : 0;
+    PassArgs a5 = pass_x(pl);
+    a5.in0 = E; a5.in1 = pl->PSIH; a5.out = pl->F;
     // Dead kx columns: E's are never written by P4 (they may hold the pair potential's stale values: B aliases E), so
     // they are always skipped; psi-hat's are exact zeros after any masked propagator, but the FIRST product of a
     // configuration sees the incoming wave, which the reference multiplies by t in full (src/multisliceSimulation.cu:546)
@@ -503,7 +492,7 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
         a5.ev_stop = ev->b;
     }
     HIPCHK(c, lds_pass(m1, XF_INV, MID_MULPSI, XF_FWD, true, a5, c->stream));
-    if (split) {
+    if (ei >= 0) {
         HIPCHK(c, hipEventRecord(pl->evP5[ei], c->stream));
         pl->p5_seen[ei] = true;
     }
@@ -511,6 +500,123 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
     a6.in0 = pl->F; a6.prow = pl->PT; a6.pcol = pl->PT + m1; a6.mindim = md; a6.out = pl->PSIH;
     a6.band = band; a6.live_rows_only = bs;
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
+    return FDES_OK;
+}
+
+// one slice of the fused loop; *consumed = slices advanced (a run of empty slices is one Fresnel step with P^n)
+int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
+{
+    *consumed = 1;
+    fdes_ctx* c = pl->ctx;
+    const int m1 = pl->p.m1, m2 = pl->p.m2;
+    // 2/3 band limit: rows/columns whose own frequency index already fails 9 i^2 <= mindim^2 are exact zeros after
+    // P4 (mask) and P6 (masked propagator): P4/P6 run only their live row groups, P3/P5 do not store the rows those
+    // never read, P5 does not load the columns they never write (pre-zeroed at plan creation).
+    const int md = m1 < m2 ? m1 : m2, band = md * md;
+    const int bs = (owner_ctx(pl)->band_skip && m1 == m2) ? 1 : 0; // the column classes of the passes assume the band of a square grid
+    auto empty = [&](int q) { return q >= pl->p.m3 || pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ]; };
+    const bool have_seg = !pl->seg_h.empty();
+    if (have_seg && empty(s)) return fused_empty_run(pl, s, nslices, consumed);
+    // the pair's potential and both transmission functions are built at the pair's first non-empty slice:
+    // C <- F_x[t_s0], C2 <- F_x[t_(s0+1)] from one read and one inverse transform of W = V_s0 + i V_(s0+1)
+    if ((s & 1) == 0 || (have_seg && empty(s - 1))) {
+        RC(fused_potential_pair(pl, s & ~1));
+        PassArgs a3 = pass_x(pl);
+        a3.in0 = pl->B; a3.out = pl->C; a3.out2 = pl->C2; a3.scale = pl->p.imPot;
+        a3.band = band; a3.skip_dead_stores = bs;
+        HIPCHK(c, lds_pass(m1, XF_INV, MID_EXPIV_PAIR, XF_FWD, true, a3, vstream(pl)));
+    }
+    const bool split = pl->split && !pl->tap_mode;
+    const int ei = s & 1;
+    PassArgs a4 = pass_y(pl);
+    a4.in0 = (s & 1) ? pl->C2 : pl->C; a4.out = pl->Eb[ei]; a4.scale = 1.f / ((float)pl->m12); a4.mindim = md;
+    a4.band = band; a4.live_rows_only = bs;
+    if (split && pl->p5_seen[ei]) HIPCHK(c, hipStreamWaitEvent(pl->vs, pl->evP5[ei], 0)); // the wave chain has consumed this buffer
+    HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, vstream(pl)));
+    if (split) {
+        HIPCHK(c, hipEventRecord(pl->evE[ei], pl->vs));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, pl->evE[ei], 0));
+    }
+    return fused_wave_step(pl, s, pl->Eb[ei], split ? ei : -1);
+}
+
+// The slices [0, nslices) of one configuration with the potential chain in BATCHES (plans with nb > 1): the potential does
+// not depend on the wave (src/crystalMaker.cu:339-343: phaseGrating takes the atoms and the slice index only), so P1',
+// P2, P3 of nb slice pairs and P4 of their 2 nb slices are one launch each (grid.z = pair resp. slice) on the potential
+// stream - a single slice's rows cannot fill the chip at 1024^2 and below, and a single image has no second
+// configuration to run beside it - while the wave stream runs P5 / P6 of the previous batch.  Empty slices take no
+// part in the batch (skip_empty); the wave chain handles their runs as fused_slice does.
+int batched_loop(fdes_plan* pl, int nslices)
+{
+    fdes_ctx* c = pl->ctx;
+    const int m1 = pl->p.m1, m2 = pl->p.m2, nZ = pl->nZ, nb = pl->nb;
+    const int md = m1 < m2 ? m1 : m2, band = md * md;
+    const int bs = (owner_ctx(pl)->band_skip && m1 == m2) ? 1 : 0;
+    const bool have_seg = !pl->seg_h.empty();
+    auto empty = [&](int q) { return q >= pl->p.m3 || pl->seg_h[(size_t)(q + 1) * nZ] == pl->seg_h[(size_t)q * nZ]; };
+    bool used[2] = {false, false};
+    int sw = 0; // next slice of the wave chain
+    int set = 0;
+    for (int s0 = 0; s0 < nslices; s0 += 2 * nb, set ^= 1) {
+        const int s1 = (s0 + 2 * nb < nslices) ? s0 + 2 * nb : nslices;
+        // ---- potential chain of the batch
+        int np = 0, ns = 0, eidx[16], zq0[16], zq1[16], zin[16];
+        for (int i = 0; i < 16; i++) eidx[i] = -1;
+        for (int sp = s0; sp < s1; sp += 2) {
+            const bool e0 = have_seg && empty(sp), e1 = (sp + 1 >= s1) || (have_seg && empty(sp + 1));
+            if (e0 && e1) continue;
+            zq0[np] = sp * nZ;
+            zq1[np] = (sp + 1 < pl->p.m3) ? (sp + 1) * nZ : -1;
+            if (!e0) { zin[ns] = 2 * np; eidx[sp - s0] = ns++; }
+            if (!e1) { zin[ns] = 2 * np + 1; eidx[sp + 1 - s0] = ns++; }
+            np++;
+        }
+        if (used[set]) HIPCHK(c, hipStreamWaitEvent(pl->vs, pl->evDone[set], 0)); // the wave chain has consumed this set
+        if (np > 0) {
+            PassArgs a1 = pass_x(pl); // P1': records -> x spectra, [pair][species] grids
+            a1.out = pl->bA; a1.nspecies = nZ; a1.species_stride = pl->gsz;
+            a1.recs = pl->bins.recs_sorted; a1.rowstart = pl->bins.rowstart;
+            a1.q0 = zq0[0]; a1.q1 = zq1[0];
+            a1.nbatch = np; a1.bstride_out = pl->gsz * (size_t)nZ;
+            for (int i = 0; i < np; i++) { a1.zq0[i] = zq0[i]; a1.zq1[i] = zq1[i]; }
+            HIPCHK(c, lds_pass(m1, XF_FWD, MID_ATOMS, XF_NONE, true, a1, pl->vs));
+            PassArgs a2 = pass_y(pl); // P2: filter, species sum -> packed pair potentials
+            a2.in0 = pl->bA; a2.gtab = pl->GT; a2.out = pl->bB; a2.nspecies = nZ; a2.species_stride = pl->gsz;
+            a2.nbatch = np; a2.bstride_in0 = pl->gsz * (size_t)nZ; a2.bstride_out = pl->gsz;
+            HIPCHK(c, lds_pass(m2, XF_FWD, nZ == 1 ? MID_GTAB : MID_GTABN, XF_INV, true, a2, pl->vs));
+            PassArgs a3 = pass_x(pl); // P3: both transmission functions of every pair -> bCC[2 pair], bCC[2 pair + 1]
+            a3.in0 = pl->bB; a3.out = pl->bCC; a3.out2 = pl->bCC + pl->gsz; a3.scale = pl->p.imPot;
+            a3.band = band; a3.skip_dead_stores = bs;
+            a3.nbatch = np; a3.bstride_in0 = pl->gsz; a3.bstride_out = 2 * pl->gsz; a3.bstride_out2 = 2 * pl->gsz;
+            HIPCHK(c, lds_pass(m1, XF_INV, MID_EXPIV_PAIR, XF_FWD, true, a3, pl->vs));
+        }
+        if (ns > 0) {
+            PassArgs a4 = pass_y(pl); // P4: band limit of the non-empty slices' transmission functions -> bE[set][slice]
+            a4.in0 = pl->bCC; a4.out = pl->bE[set]; a4.scale = 1.f / ((float)pl->m12); a4.mindim = md;
+            a4.band = band; a4.live_rows_only = bs;
+            a4.nbatch = ns; a4.use_zin = 1; a4.bstride_in0 = pl->gsz; a4.bstride_out = pl->gsz;
+            for (int i = 0; i < ns; i++) a4.zin[i] = zin[i];
+            if (ns == 1) a4.in0 = pl->bCC + (size_t)zin[0] * pl->gsz; // a batch of one is launched without the batch offsets
+            HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, pl->vs));
+        }
+        HIPCHK(c, hipEventRecord(pl->evReady[set], pl->vs));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, pl->evReady[set], 0));
+        // ---- wave chain of the batch
+        int s = sw > s0 ? sw : s0;
+        while (s < s1) {
+            if (have_seg && empty(s)) {
+                int run = 1;
+                RC(fused_empty_run(pl, s, nslices, &run));
+                s += run;
+                continue;
+            }
+            RC(fused_wave_step(pl, s, pl->bE[set] + (size_t)eidx[s - s0] * pl->gsz, -1));
+            s++;
+        }
+        sw = s;
+        HIPCHK(c, hipEventRecord(pl->evDone[set], c->stream));
+        used[set] = true;
+    }
     return FDES_OK;
 }
 
@@ -592,6 +698,8 @@ int slice_loop(fdes_plan* pl, int nslices)
         if (pl->fused) {
             RC(fused_enter(pl));
             RC(split_fork(pl));
+            if (pl->nb > 1 && !pl->tap_mode) RC(batched_loop(pl, nslices));
+            else
             for (int s = 0, adv = 1; s < nslices; s += adv) RC(fused_slice(pl, s, nslices, &adv));
             RC(split_join(pl));
             return fused_leave(pl, nslices > 0);
@@ -872,6 +980,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
     if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 64 && value != 65 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "split")) { if (value < -1 || value > 1) return FDES_EINVAL; c->split = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "batch")) { if (value < -1 || value > 8) return FDES_EINVAL; c->batch = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "stagger")) { if (value < 0 || value > 1024) return FDES_EINVAL; c->stagger = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "walk")) { if (value < 1 || value > 8) return FDES_EINVAL; c->walk = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "pitch_pad")) { if (value < -1 || value > 1024 || (value > 0 && value % 2)) return FDES_EINVAL; c->pitch_pad = (int)value; return FDES_OK; }
@@ -917,6 +1026,8 @@ int fdes_plan_destroy(fdes_plan* pl)
         for (hipEvent_t e : {pl->evE[0], pl->evE[1], pl->evP5[0], pl->evP5[1], pl->evFork, pl->evJoin}) if (e) (void)hipEventDestroy(e);
         for (void* q : {(void*)pl->Eb[1], (void*)pl->B, (void*)pl->F}) if (q) (void)hipFree(q);
     }
+    for (void* q : {(void*)pl->bA, (void*)pl->bB, (void*)pl->bCC, (void*)pl->bE[0], (void*)pl->bE[1]}) if (q) (void)hipFree(q);
+    for (hipEvent_t e : {pl->evReady[0], pl->evReady[1], pl->evDone[0], pl->evDone[1]}) if (e) (void)hipEventDestroy(e);
     fdes_params_release(&pl->p0);
     delete pl;
     return FDES_OK;
@@ -1045,6 +1156,8 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // +4 ... +6 % over 256 threads x 2 rows, A/B on one box); 4096-point rows: measured equal to 512 threads, which stay
         else if (c->pass_threads == 0 && (m1 == 2048 || m2 == 2048) && m1 <= 2048 && m2 <= 2048) pl->wg = 64;
         else pl->wg = ok256 ? 256 : 512;
+        // (mixed grids, e.g. 1000 x 512: the rows per workgroup of one axis must divide the other axis)
+        if (m2 % lds_fft_rows_per_block(m1, pl->wg) != 0 || m1 % lds_fft_rows_per_block(m2, pl->wg) != 0) pl->wg = pl->fft->wg;
         // Slice-loop working set: the transient grids share buffers (A -> [P2] -> B; B -> [P3] -> C, C2; C | C2 -> [P4] -> E;
         // E, PSIH -> [P5] -> F; F -> [P6] -> PSIH: A, C and F are never live together, nor are B and E), and the
         // lanes share the read-only tables PT / GT: 4 grids per lane + the tables instead of 7.5 per lane, so that two
@@ -1066,6 +1179,17 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // (auto: one-lane plans from 2^20 pixels on; below that the single-stream hipGraph wins: 256^2 x 32 slices 35.5 k
         // against 27.4 k slice-propagations/s, 512^2 x 32 27.6 k against 23.4 k, 1024^2 x 32 17.6 k against 19.8 k)
         pl->split = c->split > 0 || (c->split < 0 && plan_lanes(c, pl) == 1 && pl->m12 >= ((size_t)1 << 20));
+        // batched potential chain: one-lane plans whose slices cannot fill the chip by themselves (up to 2^20 pixels; a
+        // power-of-two or mixed-radix grid with the rows-per-thread kernels, i.e. not the one-wave-per-row ones)
+        {
+            int nb = 1;
+            if (plan_lanes(c, pl) == 1 && c->split != 0 && !wave_pass_supported_len(m1) && !wave_pass_supported_len(m2)) {
+                if (c->batch > 1) nb = c->batch;
+                else if (c->batch < 0) nb = pl->m12 <= ((size_t)1 << 18) ? 8 : (pl->m12 <= ((size_t)1 << 20) ? 4 : 1); // measured (tools/bench_single.py): 512^2 8 > 4 > 2; 1024^2 4 >= 2, 8 lower
+            }
+            pl->nb = nb;
+            if (nb > 1) pl->split = true;
+        }
         PLCHK(dmalloc(c, &pl->C, pl->gsz));
         if (pl->split) PLCHK(dmalloc(c, &pl->F, pl->gsz)); else pl->F = pl->C;
         if (pl->nZ == 1) pl->A = pl->C;
@@ -1085,6 +1209,18 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
                 PLHIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         } else {
             pl->B = pl->E; // the packed pair potential is consumed by P3 before P4 writes E
+        }
+        if (pl->nb > 1) {
+            const size_t nbz = (size_t)pl->nb;
+            PLCHK(dmalloc(c, &pl->bA, pl->gsz * nbz * (size_t)pl->nZ));
+            PLCHK(dmalloc(c, &pl->bB, pl->gsz * nbz));
+            PLCHK(dmalloc(c, &pl->bCC, pl->gsz * 2 * nbz));
+            for (int q = 0; q < 2; q++) {
+                PLCHK(dmalloc(c, &pl->bE[q], pl->gsz * 2 * nbz));
+                PLHIP(hipMemsetAsync(pl->bE[q], 0, sizeof(float2) * pl->gsz * 2 * nbz, c->stream)); // dead kx columns read as zero
+                PLHIP(hipEventCreateWithFlags(&pl->evReady[q], hipEventDisableTiming));
+                PLHIP(hipEventCreateWithFlags(&pl->evDone[q], hipEventDisableTiming));
+            }
         }
         PLCHK(dmalloc(c, &pl->PSIH, pl->gsz));
         if (c->share_PT) { pl->PT = c->share_PT; pl->GT = c->share_GT; pl->tables_shared = true; }
@@ -1116,7 +1252,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             PLCHK(create_ctx(&lc, c->device, nlanes >= 3 ? (l <= 2 ? l : 0) : 0));
             lc->is_lane_ctx = true;
             // frozen here: fft, lanes, pass_threads (they shape the lane plan); the others are read through owner_ctx()
-            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad; lc->split = pl->split ? 1 : 0;
+            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad; lc->split = pl->split ? 1 : 0; lc->batch = 0;
             lc->share_PT = pl->PT; lc->share_GT = pl->GT; // read-only tables of the parent plan (built and synchronised above)
             pl->lane_ctx.push_back(lc);
             fdes_plan* lp = nullptr;
@@ -1269,6 +1405,11 @@ int fdes_plan_get_images(fdes_plan* pl, float* image)
     return FDES_OK;
 }
 
+int fdes_grid_backend(int m1, int m2, int fft_option)
+{
+    if (m1 < 1 || m2 < 1) return FDES_EINVAL;
+    return (fft_option != 1 && Fft2D::lds_supported(m1, m2)) ? 2 : 1;
+}
 int fdes_plan_fft_backend(const fdes_plan* pl) { return pl ? pl->fft->backend : FDES_EINVAL; }
 int fdes_plan_lanes(const fdes_plan* pl) { return pl ? (int)pl->lanes.size() + 1 : FDES_EINVAL; }
 int fdes_plan_num_slices(const fdes_plan* pl) { return pl ? pl->p.m3 : FDES_EINVAL; }

@@ -28,6 +28,7 @@ struct Fft2D {
     int wg = 512; // workgroup geometry of the LDS passes (PassArgs::wg)
 
     static bool lds_supported(int m1, int m2);
+    static int pick_wg(int m1, int m2);
     int create(int m1, int m2, int opt, hipStream_t st, std::string* err);
     hipError_t exec(float2* data, bool inverse, hipStream_t st);
     void destroy();

@@ -9,11 +9,18 @@
 
 namespace fdes {
 
-bool Fft2D::lds_supported(int m1, int m2)
+// workgroup geometry whose rows per workgroup divide both grid dimensions (a pass over the rows of one axis has the other
+// axis' length as its row count): 512 or 256 threads x two rows per thread, or one row per thread; 0: none
+int Fft2D::pick_wg(int m1, int m2)
 {
-    if (!(lds_fft_supported_len(m1) || gen_pass_supported_len(m1)) || !(lds_fft_supported_len(m2) || gen_pass_supported_len(m2))) return false;
-    return (m2 % lds_fft_rows_per_block(m1, 512) == 0) && (m1 % lds_fft_rows_per_block(m2, 512) == 0);
+    if (!(lds_fft_supported_len(m1) || gen_pass_supported_len(m1)) || !(lds_fft_supported_len(m2) || gen_pass_supported_len(m2))) return 0;
+    for (int wg : {512, 256, 1}) {
+        if (wg == 1 && (m1 > 2048 || m2 > 2048)) continue;
+        if (m2 % lds_fft_rows_per_block(m1, wg) == 0 && m1 % lds_fft_rows_per_block(m2, wg) == 0) return wg;
+    }
+    return 0;
 }
+bool Fft2D::lds_supported(int m1, int m2) { return pick_wg(m1, m2) != 0; }
 
 static int upload_twiddles(int n, float2** tw0, float2** tw1, std::string* err)
 {
@@ -39,6 +46,7 @@ int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err)
     if (opt == 2 && !lds_ok) { if (err) *err = "hand-written FFT needs grid lengths 256 ... 4096 that are powers of two, or 2^a 3^b 5^c up to 2048"; return -1; }
     backend = (opt == 1 || !lds_ok) ? 1 : 2;
     if (backend == 2) {
+        wg = pick_wg(m1, m2);
         if (upload_twiddles(m1, &tw0x, &tw1x, err)) return -1;
         if (upload_twiddles(m2, &tw0y, &tw1y, err)) return -1;
         if (hipMalloc((void**)&scratch, sizeof(float2) * (size_t)m1 * m2) != hipSuccess) { if (err) *err = "scratch allocation failed"; return -1; }

@@ -25,12 +25,19 @@ namespace {
 
 struct GenFac {
     int n = 0;       // row length
-    int rows = 0;    // rows per workgroup
+    int rows = 0;    // rows per workgroup (4 or 8)
+    int lrows = 0;   // log2(rows)
     int nf = 0;      // stages
     int radix[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // per stage: butterflies per row n / radix, sub-transform length Ns so far, table step n / (Ns radix) of its twiddle,
+    // ceil(2^32 / Ns) (j / Ns = umulhi(j, magic) for j < 2^16: the kernels never divide)
+    int nbf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ns[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tws[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned magic[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
-constexpr int kGenThreads = 256;
+// 512 threads = 8 waves per workgroup (two workgroups per CU at 1000 points: 2 waves per SIMD hide the LDS round trips
+// of the stages); a row belongs to 512 / rows consecutive threads
+constexpr int kGenThreads = 512;
 
 // s = +1 forward, -1 inverse: multiply by -i (forward) / +i (inverse)
 __device__ __forceinline__ cf mi_s(cf a, float s) { return cf{a.y * s, -a.x * s}; }
@@ -112,28 +119,28 @@ __device__ __forceinline__ void dft10(cf (&x)[10], float s)
     x[4] = e4 + o4; x[9] = e4 - o4;
 }
 
-// One Stockham stage of radix RX over the R rows of the tile: work item = (row, butterfly j), inputs src[j + i N/RX],
-// twiddle W_N^(i k N / (Ns RX)) with k = j mod Ns, outputs dst[(j / Ns) Ns RX + k + i Ns].
+// One Stockham stage of radix RX over the R rows of the tile: butterfly j of a row takes src[j + i N/RX], twiddles
+// W_N^(i k N / (Ns RX)) with k = j mod Ns, and leaves dst[(j / Ns) Ns RX + k + i Ns].  `row` / `jt` / `tpr`: this thread's
+// row, its index among the tpr threads of that row.
 template <int RX>
-__device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __restrict__ dst, const cf* __restrict__ twl, const int N, const int R,
-                                          const int Ns, const float s)
+__device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __restrict__ dst, const cf* __restrict__ twl, const int N, const int nb,
+                                          const int Ns, const int tws, const unsigned magic, const float s, const int row, const int jt,
+                                          const int tpr)
 {
-    const int nb = N / RX;          // butterflies per row
-    const int tws = N / (Ns * RX);  // table step of this stage's twiddle
-    for (int wi = threadIdx.x; wi < R * nb; wi += kGenThreads) {
-        const int row = wi / nb, j = wi - row * nb;
-        const int k = j % Ns;
-        const cf* __restrict__ in = src + row * N + j;
+    const cf* __restrict__ srow = src + row * N;
+    cf* __restrict__ drow = dst + row * N;
+    for (int j = jt; j < nb; j += tpr) {
+        const int k = (Ns > 1) ? j - (int)__umulhi((unsigned)j, magic) * Ns : 0;
         cf x[10];
 #pragma unroll
-        for (int i = 0; i < RX; i++) x[i] = in[i * nb];
+        for (int i = 0; i < RX; i++) x[i] = srow[j + i * nb];
         if (Ns > 1) {
             int ti = 0; // (i k tws) mod N, built incrementally
             const int dk = k * tws;
 #pragma unroll
             for (int i = 1; i < RX; i++) {
                 ti += dk;
-                if (ti >= N) ti -= N;
+                ti -= (ti >= N) ? N : 0;
                 const cf w = twl[ti];
                 x[i] = cf{x[i].x * w.x + x[i].y * (w.y * -s), x[i].y * w.x + x[i].x * (w.y * s)}; // * w (forward) or conj(w) (inverse)
             }
@@ -144,7 +151,7 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
         if constexpr (RX == 5) dft5(x, s);
         if constexpr (RX == 8) dft8(x, s);
         if constexpr (RX == 10) dft10(x, s);
-        cf* __restrict__ out = dst + row * N + (j - k) * RX + k;
+        cf* __restrict__ out = drow + (j - k) * RX + k;
 #pragma unroll
         for (int i = 0; i < RX; i++) out[i * Ns] = x[i];
     }
@@ -154,29 +161,28 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
 __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restrict__ twl, const GenFac& F, const bool inverse)
 {
     const float s = inverse ? -1.f : 1.f;
-    int Ns = 1;
+    const int tpr = kGenThreads >> F.lrows, row = (int)threadIdx.x / tpr, jt = (int)threadIdx.x - row * tpr; // tpr is a power of two
     for (int q = 0; q < F.nf; q++) {
         const int rx = F.radix[q];
         switch (rx) {
-        case 2: gen_stage<2>(cur, other, twl, F.n, F.rows, Ns, s); break;
-        case 3: gen_stage<3>(cur, other, twl, F.n, F.rows, Ns, s); break;
-        case 4: gen_stage<4>(cur, other, twl, F.n, F.rows, Ns, s); break;
-        case 5: gen_stage<5>(cur, other, twl, F.n, F.rows, Ns, s); break;
-        case 8: gen_stage<8>(cur, other, twl, F.n, F.rows, Ns, s); break;
-        default: gen_stage<10>(cur, other, twl, F.n, F.rows, Ns, s); break;
+        case 2: gen_stage<2>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+        case 3: gen_stage<3>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+        case 4: gen_stage<4>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+        case 5: gen_stage<5>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+        case 8: gen_stage<8>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+        default: gen_stage<10>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         }
         __syncthreads();
         cf* t_ = cur; cur = other; other = t_;
-        Ns *= rx;
     }
 }
 
 // (float)(i1^2 + i2^2) * 9 / mindim^2 > 1: zeroHighFreq's test (src/multisliceSimulation.cu:241)
 __device__ __forceinline__ bool gen_outside(int i1, int i2, float md) { return ((float)(i1 * i1 + i2 * i2) * 9.f / (md * md)) > 1.f; }
 
-// EPT: elements a thread owns (element e = tid + 256 i of the R x N tile, row-major)
+// EPT: elements a thread owns (element e = tid + 512 i of the R x N tile, row-major)
 template <int EPT, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(kGenThreads) void k_gpass(PassArgs A, GenFac F)
+__global__ __launch_bounds__(kGenThreads, (EPT <= 8 ? 4 : 2)) void k_gpass(PassArgs A, GenFac F) // EPT <= 8 (rows up to 1024 points): two workgroups per CU
 {
     extern __shared__ cf glds[];
     const int N = F.n, R = F.rows, tid = threadIdx.x;
@@ -199,15 +205,19 @@ __global__ __launch_bounds__(kGenThreads) void k_gpass(PassArgs A, GenFac F)
     const unsigned pin = A.pitch_in ? (unsigned)A.pitch_in : (unsigned)N;
     const unsigned ldt = A.pitch_out ? (unsigned)A.pitch_out : (unsigned)A.nrows;
     const size_t gbase = (size_t)row0 * pin;
-    const cf* __restrict__ in0 = A.in0 ? reinterpret_cast<const cf*>(A.in0) + gbase : nullptr;
+    // batch of grids in one launch (grid.z, PassArgs::nbatch): this workgroup's grid
+    const int bz = (int)blockIdx.z;
+    const size_t zoff_in = (A.nbatch > 1) ? (size_t)(A.use_zin ? A.zin[bz] : bz) * A.bstride_in0 : (size_t)0;
+    const size_t zoff_out = (A.nbatch > 1) ? (size_t)bz * A.bstride_out : (size_t)0;
+    const cf* __restrict__ in0 = A.in0 ? reinterpret_cast<const cf*>(A.in0) + gbase + zoff_in : nullptr;
     const cf* __restrict__ in1 = A.in1 ? reinterpret_cast<const cf*>(A.in1) + gbase : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
-    cf* const out0 = reinterpret_cast<cf*>(A.out) + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0);
+    cf* const out0 = reinterpret_cast<cf*>(A.out) + zoff_out + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0);
     if constexpr (PRE != XF_NONE || POST != XF_NONE) {
         const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
         for (int i = tid; i < N; i += kGenThreads) twl[i] = tw[i];
     }
-    // this thread's elements: (row, column) of e = tid + 256 i; N >= 256, so a step wraps at most once
+    // this thread's elements: (row, column) of e = tid + 512 i; N >= 256, so a step wraps at most twice
     int er[EPT], ec[EPT];
     {
         int r = tid / N, c = tid - r * N;
@@ -216,6 +226,7 @@ __global__ __launch_bounds__(kGenThreads) void k_gpass(PassArgs A, GenFac F)
             er[i] = r;
             ec[i] = c;
             c += kGenThreads;
+            if (c >= N) { c -= N; r++; }
             if (c >= N) { c -= N; r++; }
         }
     }
@@ -264,7 +275,8 @@ __global__ __launch_bounds__(kGenThreads) void k_gpass(PassArgs A, GenFac F)
             int plo[2] = {0, 0}, phi[2] = {0, 0};
 #pragma unroll
             for (int comp = 0; comp < 2; comp++) {
-                const int q = (comp ? A.q1 : A.q0) < 0 ? -1 : (comp ? A.q1 : A.q0) + (int)blockIdx.y;
+                const int qb = (A.nbatch > 1) ? (comp ? A.zq1[bz] : A.zq0[bz]) : (comp ? A.q1 : A.q0);
+                const int q = qb < 0 ? -1 : qb + (int)blockIdx.y;
                 if (q >= 0) {
                     const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
                     plo[comp] = rs[rlo];
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(kGenThreads) void k_gpass(PassArgs A, GenFac F)
             }
             if (phi[0] - plo[0] + phi[1] - plo[1] == 0) { // workgroup-uniform: the spectrum of an empty row group is zero
                 if constexpr (STORE_T) {
-                    for (int e = tid; e < tile; e += kGenThreads) (out0 + row0)[(unsigned)(e / R) * ldt + (unsigned)(e % R)] = cf{0.f, 0.f};
+                    for (int e = tid; e < tile; e += kGenThreads) (out0 + row0)[(unsigned)(e >> F.lrows) * ldt + (unsigned)(e & (R - 1))] = cf{0.f, 0.f};
                 }
                 return;
             }
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(kGenThreads) void k_gpass(PassArgs A, GenFac F)
             // transposed grid: N rows of length ldt; consecutive threads write the R consecutive elements of one output row
             cf* __restrict__ dst = outp + row0;
             for (int e = tid; e < tile; e += kGenThreads) {
-                const int c = e / R, rr = e - c * R;
+                const int c = e >> F.lrows, rr = e & (R - 1);
                 if (A.skip_dead_stores && dead_index(iwc(c, N), A.band)) continue;
                 dst[(unsigned)c * ldt + (unsigned)rr] = cur[rr * N + c];
             }
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(kGenThreads) void k_gpass(PassArgs A, GenFac F)
             }
         __syncthreads();
         if constexpr (POST != XF_NONE) gen_fft(cur, other, twl, F, POST == XF_INV);
-        store_tile(reinterpret_cast<cf*>(A.out2));
+        store_tile(reinterpret_cast<cf*>(A.out2) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_out2 : (size_t)0));
     }
 }
 
@@ -402,7 +414,16 @@ bool factorize(int n, GenFac& f)
             f.radix[f.nf++] = cand[ci];
             m /= cand[ci];
         }
-    return m == 1;
+    if (m != 1) return false;
+    int Ns = 1;
+    for (int q = 0; q < f.nf; q++) {
+        f.nbf[q] = n / f.radix[q];
+        f.ns[q] = Ns;
+        f.tws[q] = n / (Ns * f.radix[q]);
+        f.magic[q] = (unsigned)(((1ull << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
+        Ns *= f.radix[q];
+    }
+    return true;
 }
 
 int gen_rows(int n) { return n > 512 ? 4 : 8; }
@@ -435,12 +456,14 @@ template <int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaunch(const
         else w.live_rows_only = 0;
     }
     const int ny = (MID == MID_ATOMS) ? (a.nspecies > 0 ? a.nspecies : 1) : 1;
+    if (a.nbatch > 16) return hipErrorInvalidValue;
+    const int nz = a.nbatch > 1 ? a.nbatch : 1;
     if (a.ev_start && a.ev_stop) {
         w.ev_start = w.ev_stop = nullptr;
-        hipExtLaunchKernelGGL(kern, dim3(groups, ny), dim3(kGenThreads), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w, f);
+        hipExtLaunchKernelGGL(kern, dim3(groups, ny, nz), dim3(kGenThreads), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w, f);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(groups, ny), dim3(kGenThreads), lds_bytes, st, w, f);
+    hipLaunchKernelGGL(kern, dim3(groups, ny, nz), dim3(kGenThreads), lds_bytes, st, w, f);
     return hipGetLastError();
 }
 
@@ -492,9 +515,10 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
     GenFac f;
     if (!gen_pass_supported_len(n) || !factorize(n, f)) return hipErrorInvalidValue;
     f.rows = gen_rows(n);
+    f.lrows = f.rows == 4 ? 2 : 3;
     const int ept = (f.rows * n + kGenThreads - 1) / kGenThreads;
+    if (ept <= 8) return gdispatch<8>(pre, mid, post, st_t, a, f, st);
     if (ept <= 16) return gdispatch<16>(pre, mid, post, st_t, a, f, st);
-    if (ept <= 32) return gdispatch<32>(pre, mid, post, st_t, a, f, st);
     return hipErrorInvalidValue;
 }
 

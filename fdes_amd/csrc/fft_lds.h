@@ -74,6 +74,14 @@ struct PassArgs {
     const void* recs = nullptr;  // AtomRec[] sorted by (slice, species, row)
     const int* rowstart = nullptr; // [q][nrows + 1]
     int q0 = -1, q1 = -1;        // (slice * nZ + species) deposited into the real / imaginary component (-1: none)
+    // Batch of independent grids in ONE launch (grid.z = nbatch <= 16; fft_lds.hip and fft_gen.hip): grid z reads
+    // in0 + (use_zin ? zin[z] : z) * bstride_in0 and writes out + z * bstride_out (out2 + z * bstride_out2); MID_ATOMS:
+    // q0 / q1 = zq0[z] / zq1[z].  The potential / transmission passes of several slice pairs of ONE configuration run this
+    // way (a single image at 1024^2 and below cannot fill the chip with one slice's rows).
+    int nbatch = 1, use_zin = 0;
+    size_t bstride_in0 = 0, bstride_out = 0, bstride_out2 = 0;
+    int zin[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int zq0[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, zq1[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // diagnostic builds (-DFDES_STAMPS): per wave, 16 shader-clock stamps of the pass's phases (tools/stamps.py)
     unsigned long long* dbg = nullptr;
     // host side only: when set, the dispatch is bracketed by these two events through hipExtLaunchKernelGGL, whose

@@ -387,11 +387,15 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
         grow[h] = row0 + r + h * RH;
         rbase[h] = (unsigned)(r + h * RH) * pin;
     }
-    const float2* __restrict__ in0 = A.in0 ? reinterpret_cast<const float2*>(A.in0) + gbase : nullptr;
+    // batch of grids in one launch (grid.z, PassArgs::nbatch): this workgroup's grid
+    const int bz = (int)blockIdx.z;
+    const size_t zoff_in = (A.nbatch > 1) ? (size_t)(A.use_zin ? A.zin[bz] : bz) * A.bstride_in0 : (size_t)0;
+    const size_t zoff_out = (A.nbatch > 1) ? (size_t)bz * A.bstride_out : (size_t)0;
+    const float2* __restrict__ in0 = A.in0 ? reinterpret_cast<const float2*>(A.in0) + gbase + zoff_in : nullptr;
     const float2* __restrict__ in1 = A.in1 ? reinterpret_cast<const float2*>(A.in1) + gbase : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
     float2* __restrict__ zsrc = A.zsrc ? reinterpret_cast<float2*>(A.zsrc) + gbase : nullptr;
-    float2* const out0 = reinterpret_cast<float2*>(A.out) + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0); // MID_ATOMS: one launch covers every species
+    float2* const out0 = reinterpret_cast<float2*>(A.out) + zoff_out + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0); // MID_ATOMS: one launch covers every species
 
     float2 a[WGeo<WG>::NRV][16];
     float2 b[(MID == MID_MULPSI) ? WGeo<WG>::NRV : 1][16]; // second operand
@@ -435,7 +439,8 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
             int plo[2] = {0, 0}, phi[2] = {0, 0};
 #pragma unroll
             for (int comp = 0; comp < 2; comp++) {
-                const int q = (comp ? A.q1 : A.q0) < 0 ? -1 : (comp ? A.q1 : A.q0) + (int)blockIdx.y; // blockIdx.y = species
+                const int qb = (A.nbatch > 1) ? (comp ? A.zq1[bz] : A.zq0[bz]) : (comp ? A.q1 : A.q0);
+                const int q = qb < 0 ? -1 : qb + (int)blockIdx.y; // blockIdx.y = species
                 if (q >= 0) {
                     const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
                     plo[comp] = rs[rlo];
@@ -679,7 +684,7 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
         pair_transmission(a, A.scale);
         __syncthreads(); // every wave is done with the transpose tile before the second transform writes the row buffers
         xform<N, WG, POST, true, TWR>(a, lds, r, t, tw, gs);
-        store_rows(a, reinterpret_cast<float2*>(A.out2));
+        store_rows(a, reinterpret_cast<float2*>(A.out2) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_out2 : (size_t)0));
     }
 }
 
@@ -719,13 +724,15 @@ template <int N, int WG, int PRE, int MID, int POST, bool ST> hipError_t launch(
         const int L = a.band_L;
         const int g_lo = L / G_::R + 1, g_hi = (a.nrows - L) / G_::R;
         if (g_hi > g_lo) groups = g_lo + (a.nrows / G_::R - g_hi); // else: everything is live
-        else { PassArgs b = a; b.live_rows_only = 0; b.walk = 1; hipLaunchKernelGGL(kern, dim3(groups), dim3(WGeo<WG>::THR), lds_bytes, st, b); return hipGetLastError(); }
+        else { PassArgs b = a; b.live_rows_only = 0; b.walk = 1; hipLaunchKernelGGL(kern, dim3(groups, 1, a.nbatch > 1 ? a.nbatch : 1), dim3(WGeo<WG>::THR), lds_bytes, st, b); return hipGetLastError(); }
     }
     PassArgs w = a;
     const int ny = (MID == MID_ATOMS) ? (a.nspecies > 0 ? a.nspecies : 1) : 1; // grid.y = species (q0 / q1 are those of species 0, the grids are species_stride apart)
+    if (a.nbatch > 16) return hipErrorInvalidValue;
+    const int nz = a.nbatch > 1 ? a.nbatch : 1;                                   // grid.z = batch
     if (a.ev_start && a.ev_stop) { // timed launch: always whole
         w.ev_start = w.ev_stop = nullptr;
-        hipExtLaunchKernelGGL(kern, dim3(groups, ny), dim3(WGeo<WG>::THR), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w);
+        hipExtLaunchKernelGGL(kern, dim3(groups, ny, nz), dim3(WGeo<WG>::THR), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w);
         return hipGetLastError();
     }
     int chunk = groups;
@@ -736,7 +743,7 @@ template <int N, int WG, int PRE, int MID, int POST, bool ST> hipError_t launch(
     if (chunk < groups) w.nvirt = groups;
     for (int v0 = 0; v0 < groups; v0 += chunk) {
         w.vb0 = v0;
-        hipLaunchKernelGGL(kern, dim3(chunk < groups - v0 ? chunk : groups - v0, ny), dim3(WGeo<WG>::THR), lds_bytes, st, w);
+        hipLaunchKernelGGL(kern, dim3(chunk < groups - v0 ? chunk : groups - v0, ny, nz), dim3(WGeo<WG>::THR), lds_bytes, st, w);
     }
     return hipGetLastError();
 }

@@ -72,6 +72,9 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     } else if (const char* e = std::getenv("FDES_NUM_GPUS")) {
         for (int i = 0; i < std::atoi(e); i++) devices.push_back(gpu_index + i);
     }
+    if (rc == FDES_OK)
+        std::fprintf(stderr, "  Wave %d x %d, slice loop: %s\n", p0.m1, p0.m2,
+                     fdes_grid_backend(p0.m1, p0.m2, 0) == 2 ? "fused LDS passes" : "rocFFT + point-wise kernels");
     if (rc == FDES_OK && devices.size() > 1) {
         const size_t m12 = (size_t)p0.m1 * p0.m2;
         image.resize((size_t)p0.n1 * p0.n2 * p0.n3);

@@ -189,6 +189,8 @@ int fdes_plan_get_images(fdes_plan* plan, float* image);
 int fdes_plan_sync(fdes_plan* plan);
 /* 1: generic slice loop on rocFFT + point-wise kernels; 2: fused LDS-pass slice loop. */
 int fdes_plan_fft_backend(const fdes_plan* plan);
+/* The same question for a grid of m1 x m2 points before any plan exists (host only; fft_option as engine option "fft"). */
+int fdes_grid_backend(int m1, int m2, int fft_option);
 /* Configurations the plan keeps in flight at once (lanes: own HIP stream and buffers each; option "lanes"). */
 int fdes_plan_lanes(const fdes_plan* plan);
 /* Number of (sub-)slices m3 after sub-slicing; slice-propagations done so far. */
@@ -214,6 +216,9 @@ int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
  *   "split"      -1 (default): a plan with one lane (single-image jobs; a plan never has more lanes than the job has
  *                configurations) and at least 2^20 pixels runs the potential / transmission passes of its slice loop on a second stream, one
  *                slice pair ahead of the wave's passes; 0 never, 1 always
+ *   "batch"      -1 (default): a one-lane plan of at most 2^20 pixels runs the potential / transmission passes of 4 (1024^2)
+ *                or 8 (512^2 and below) slice pairs as one launch each, a batch ahead of the wave's passes;
+ *                0 / 1 off, 2 ... 8 pairs per launch
  *   "pitch_pad"  -1 (default: 32 for 2048-point rows, 64 from 4096 on) elements of padding per row of the slice loop's grids
  *   "walk"       1 (default) .. 8: launch every pass in that many parts
  *   "deterministic"  1 (default): the deposit of the rocFFT slice loop and of the potential output adds the atoms in sorted

@@ -249,7 +249,7 @@ def test_full_size_propagation_properties(engine):
 def test_shipped_au309_example_through_the_cli(oracle, tmp_path):
     """The reference's own example (ExampleSpecimens/Au_cubeoctahedron_emd/Auparticle.emd: 309 Au atoms, 320^2 wave,
     12 slices -> 132 sub-slices, 25 specimen tilts, pixel dose 100) through the FDES command line: .emd reader,
-    non-power-of-two grid (rocFFT path), sub-slicing, tilts, detector chain with Poisson surrogate noise,
+    non-power-of-two grid (320 = 2^6 5: mixed-radix fused passes since round 3), sub-slicing, tilts, detector chain with Poisson surrogate noise,
     Measurements.bin + results.emd writers."""
     import subprocess
     src = os.path.join(G, "Auparticle_config.emd")
@@ -257,6 +257,7 @@ def test_shipped_au309_example_through_the_cli(oracle, tmp_path):
     r = subprocess.run([os.path.abspath(exe), "--input_name", src, "--image_name", "Measurements.bin", "--emd_name", "results.emd"],
                        cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert "Wave 320 x 320, slice loop: fused LDS passes" in r.stderr  # round 3: mixed-radix passes, fft_backend == 2
     hp, at = fdes_amd.read_emd(src)
     img = np.fromfile(tmp_path / "Measurements.bin", np.float32).reshape(hp.c.n3, hp.c.n2, hp.c.n1)
     ref = oracle.build_measurements(hp, at, prec="f32")["image"]
@@ -408,13 +409,14 @@ def test_edge_cases_match_the_oracle(engine, oracle, kind):
 def test_shipped_si001_example_through_the_cli(oracle, tmp_path):
     """The reference's ExampleSpecimens/Si_001_11k_cnf/dataFDES_11k.cnf (11 552 Si atoms, 1000^2 wave = 2^3 5^3 points
     per side, 205 slices of 0.1 A, 100 kV, no aperture cut) through the FDES command line and the bug-compatible
-    .cnf reader: rocFFT path with the packed pair potential, Measurements.bin against the float32 oracle."""
+    .cnf reader: mixed-radix fused passes (rocFFT path before round 3), Measurements.bin against the float32 oracle."""
     import subprocess
     src = os.path.join(G, "dataFDES_Si001_11k.cnf")
     exe = os.path.abspath(os.path.join(os.path.dirname(G), "..", "fdes_amd", "csrc", "FDES"))
     r = subprocess.run([exe, "--input_name", src, "--image_name", "Measurements.bin", "--emd_name", "results.emd"],
                        cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert "Wave 1000 x 1000, slice loop: fused LDS passes" in r.stderr  # round 3: mixed-radix passes, fft_backend == 2
     hp, at = fdes_amd.read_cnf(src)
     assert (hp.c.m1, hp.c.m2, hp.c.m3, hp.c.n1) == (1000, 1000, 205, 660) and at.n in (11552, 11553)  # +1: duplicated last atom quirk
     img = np.fromfile(tmp_path / "Measurements.bin", np.float32).reshape(1, 660, 660)
@@ -490,7 +492,7 @@ def test_randomised_parameter_sweep(engine, oracle, seed):
 
 def test_shipped_qsc_example_through_the_cli(oracle, tmp_path):
     """The reference's bin/test.qsc as shipped: SrTiO3 9x9x20 cells (8 100 atoms, three species), nx = 400 -> 800^2 wave
-    (rocFFT path), 40 slices cut into 400 sub-slices, CBED probe (cal_mode 2), pixel dose 10 -> Poisson surrogate noise;
+    (mixed-radix fused passes), 40 slices cut into 400 sub-slices, CBED probe (cal_mode 2), pixel dose 10 -> Poisson surrogate noise;
     FDES CLI against the float32 oracle with the same Philox streams."""
     import subprocess
     src = os.path.join(G, "qsc", "test.qsc")
@@ -498,6 +500,7 @@ def test_shipped_qsc_example_through_the_cli(oracle, tmp_path):
     r = subprocess.run([exe, "--input_name", src, "--image_name", "Measurements.bin", "--emd_name", "results.emd"],
                        cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert "Wave 800 x 800, slice loop: fused LDS passes" in r.stderr  # round 3: mixed-radix passes, fft_backend == 2
     hp, at = fdes_amd.read_qsc(src)
     assert (hp.c.m1, hp.c.m3, hp.c.mode, at.n) == (800, 40, 2, 8100)
     img = np.fromfile(tmp_path / "Measurements.bin", np.float32).reshape(1, 400, 400)

@@ -355,22 +355,33 @@ def test_dense_specimen_stops_asking_for_empty_slices(oracle):
 
 
 @pytest.mark.parametrize("kw", [dict(m=256, m3=6, nz=2, frPh=4, nat=150, tilt=True), dict(m=256, m3=4, nz=2, mode=2, nat=80),
-                                dict(m=1024, m3=5, nz=3, frPh=3, nat=300, beam_tilt=True, n3=2)])
+                                dict(m=1024, m3=5, nz=3, frPh=3, nat=300, beam_tilt=True, n3=2),
+                                dict(m=320, m3=6, nz=2, frPh=3, nat=200, tilt=True), dict(m=800, m3=4, nz=2, mode=2, nat=150),
+                                dict(m=2048, m3=4, nz=2, frPh=2, nat=300), dict(m=308, m3=4, nz=2, frPh=2, nat=150, fft=1),
+                                dict(m=256, m3=4, nz=2, frPh=2, nat=150, fft=1)])
 def test_fused_path_is_bit_reproducible(kw):
     """Two runs of the same simulation on the fused path give the same bits: the deposits go through single-wave LDS
     atomics in sorted order, lanes are dealt round-robin and folded in lane order, graphs replay fixed launch sequences,
-    and the CBED probe norm is a fixed-order two-stage sum (round 1: float atomicAdd across blocks).  (NOT claimed for
-    the generic rocFFT path: its deposit uses global float atomics, as the reference's does.)"""
+    and the CBED probe norm is a fixed-order two-stage sum (round 1: float atomicAdd across blocks).  Round 3: the same
+    for the mixed-radix grids (320, 800), the one-wave-per-row passes (2048) and the rocFFT path (fft = 1, and 308 = 2^2 7 11
+    which no hand-written kernel serves): its deposit now adds the atoms in sorted order through an LDS tile, and the
+    potential output of print_level 1 with it."""
+    kw = dict(kw)
+    fft = kw.pop("fft", 0)
     hp, at = S.case_tiny(**kw)
     fdes_amd.consistent(hp)
     outs = []
     for rep in range(3):
-        eng = fdes_amd.Engine(0)
-        outs.append(eng.build_measurements(hp, at, want_exitwave=True))
+        eng = fdes_amd.Engine(0, fft=fft)
+        pl = eng.plan(hp, at)
+        assert pl.fft_backend() == (1 if fft == 1 else 2)
+        pl.close()
+        outs.append(eng.build_measurements(hp, at, want_exitwave=True, want_potential=True))
         eng.close()
     for o in outs[1:]:
         assert np.array_equal(o["image"].view(np.uint32), outs[0]["image"].view(np.uint32))
         assert np.array_equal(o["exitwave"].view(np.uint32), outs[0]["exitwave"].view(np.uint32))
+        assert np.array_equal(o["potential"].view(np.uint32), outs[0]["potential"].view(np.uint32))
 
 
 def test_fft_option_is_part_of_the_plan_cache_key():

@@ -573,3 +573,12 @@ def test_bench_deals_every_configuration_once_and_starts_its_own_ranks():
                          capture_output=True, text=True, timeout=120)
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["rank"] == 1 and lines[0]["timed_j"] == [1, 3]
+
+
+def test_pipelined_kernels_never_read_a_landing_register_early():
+    """fft_wave.hip, pass_threads = 65: look-ahead operands are loaded into accumulation registers by inline assembly that
+    the compiler's s_waitcnt insertion does not see; tools/check_acc_landing.py compiles the file to assembly and verifies
+    that no compiler-generated instruction reads such a register and that these kernels have no scratch traffic."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_acc_landing.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok   k_wpass<") >= 20

@@ -4,7 +4,7 @@
 #   PMC traffic and SQ counters (one run per counter group, never combined with tracing domains other than the kernel
 #   trace) for 2048^2 and 4096^2.            usage: tools/profile_round.sh r02
 set -e
-R=${1:-r02}
+R=${1:-r03}
 O=$PWD/gpurun_out/prof_$R
 mkdir -p $O
 export TMPDIR=/tmp
@@ -27,6 +27,16 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc2048/g$i -o p -- $P2048 > $O/pmc2048_g$i.log 2>&1
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc4096/g$i -o p -- $P4096 > $O/pmc4096_g$i.log 2>&1
+  echo "   group $i done"
+done
+# memory-side view (round 3): L2 hit / miss and the fabric (EA) requests behind it; which of these exist on this box is
+# recorded in $O/counters_available.txt.  A group that the profiler refuses is skipped, not fatal.
+rocprofv3 -L > $O/counters_all.txt 2>&1 || true
+grep -i -E "TCC_HIT|TCC_MISS|TCC_EA0?_(RD|WR)REQ|MALL|TCC_REQ|TCC_BUBBLE|HBM" $O/counters_all.txt | head -80 > $O/counters_available.txt || true
+for grp in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc2048/g$i -o p -- $P2048 > $O/pmc2048_g$i.log 2>&1 || echo "   group $i ($grp) refused at 2048"
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc4096/g$i -o p -- $P4096 > $O/pmc4096_g$i.log 2>&1 || echo "   group $i ($grp) refused at 4096"
   echo "   group $i done"
 done
 cd $Q
