@@ -184,9 +184,15 @@ def main():
             kname, alg_bytes = f"rocFFT 2-D C2C {m}x{m} (row + column kernels)", 32.0 * px
         ach = alg_bytes / per_launch_s / 1e9
         traffic, stale = pmc_traffic(m) if fused else (None, False)
+        cold = hbm_cold_launch(m, local) if (fused and m in (2048, 4096)) else None
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_stale": stale,
                 "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": int(fft_n),
+                # the same kernel with its operands in HBM only (8 buffer sets round-robin on one stream, 1.2 GB at 2048^2:
+                # beyond the 256 MiB Infinity Cache, whose hits no rocprofv3 counter of this box exposes); `frac` above is
+                # measured inside the slice loop, where part of the traffic is served by that cache
+                "hbm_cold": (None if cold is None else {"launch_us": round(cold, 2), "achieved": round(alg_bytes / cold / 1e3, 1),
+                                                         "hbm_frac": round(alg_bytes / (cold * 1e-6) / 8e12, 4)}),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "timed": "HIP start/stop events of the dispatch itself (hipExtLaunchKernelGGL) on every %d-th launch during one "
                          "configuration run on lane 0 right after the timed steps (other lanes idle)" % args.probe_stride}
@@ -298,6 +304,18 @@ def pmc_traffic(m):
     except Exception:
         pass
     return None, False
+
+
+def hbm_cold_launch(m, device):
+    """Mean launch time [us] of P5 (same band bookkeeping, row padding and workgroup geometry as the slice loop) over 8
+    buffer sets used round-robin on ONE stream: every launch finds its operands in HBM only (tools/bench_mall.py)."""
+    import fdes_amd
+    eng = fdes_amd.Engine(device, bench_band=6, bench_pitch=32 if m == 2048 else 64, bench_serial=1,
+                          pass_threads=64 if m == 2048 else 512)
+    try:
+        return eng.bench_pass(m, 2, 5, 1, 1, 60, 8)
+    finally:
+        eng.close()
 
 
 def run_extras(device):

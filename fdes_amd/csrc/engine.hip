@@ -42,6 +42,7 @@ struct fdes_ctx {
     int bench_alt = -1;   // fdes_bench_pass only: >= 0: odd streams run pass (alt / 10000, alt / 100 % 100, alt % 100) instead
     int bench_tall = 1;   // fdes_bench_pass only: rows = bench_tall * n (emulates a batch of configurations in one launch)
     int bench_pitch = 0;  // fdes_bench_pass only: rows of every scratch grid are padded by this many elements
+    int bench_serial = 0; // fdes_bench_pass only: the `streams` buffer sets are used round-robin on ONE stream (a footprint beyond the Infinity Cache without concurrency)
     float2* share_PT = nullptr; // lane contexts: tables owned by the parent plan (PT: separable propagator, px[m1] | py[m2])
     float* share_GT = nullptr;
     int band_skip = 1;    // do not move / transform the rows and columns the 2/3 band limit zeroes anyway
@@ -988,6 +989,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "bench_alt")) { c->bench_alt = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_tall")) { if (value < 1 || value > 4) return FDES_EINVAL; c->bench_tall = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "bench_band")) { c->bench_band = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "bench_serial")) { c->bench_serial = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "bench_pitch")) { if (value < 0 || value > 4096) return FDES_EINVAL; c->bench_pitch = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "skip_empty")) { c->skip_empty = value != 0; return FDES_OK; }
@@ -1762,8 +1764,8 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
     if (rc == FDES_OK) {
         hipError_t e = hipSuccess;
         auto go = [&](int q) {
-            if (c->bench_alt >= 0 && (q & 1)) return lds_pass(n, c->bench_alt / 10000, c->bench_alt / 100 % 100, c->bench_alt % 100, store_t != 0, args[q], sts[q]);
-            return lds_pass(n, pre, mid, post, store_t != 0, args[q], sts[q]);
+            if (c->bench_alt >= 0 && (q & 1)) return lds_pass(n, c->bench_alt / 10000, c->bench_alt / 100 % 100, c->bench_alt % 100, store_t != 0, args[q], c->bench_serial ? sts[0] : sts[q]);
+            return lds_pass(n, pre, mid, post, store_t != 0, args[q], c->bench_serial ? sts[0] : sts[q]);
         };
         for (int q = 0; q < streams && e == hipSuccess; q++) e = go(q);
         (void)hipDeviceSynchronize();

@@ -51,7 +51,7 @@ int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_
 /* Engine options for tests and benches only (fdes_set_option):
  *   "probe_stride"  n > 0: bracket every n-th launch of the dominant kernel with HIP events (fdes_plan_probe_ms)
  *   "lanes_active"  n > 0: run_config deals only to the first n lanes from now on (0: all)
- *   "bench_band", "bench_alt", "bench_tall", "bench_pitch"  shape fdes_bench_pass only */
+ *   "bench_band", "bench_alt", "bench_tall", "bench_pitch", "bench_serial"  shape fdes_bench_pass only */
 
 #ifdef __cplusplus
 }

@@ -196,3 +196,67 @@ def test_mixed_radix_driver_images(oracle, kw):
     e, er = relerr(img, ref), relerr(img_r, ref)
     print(f"[parity] mixed-radix driver {kw}: E(fused) = {e:.3e}, E(rocFFT path) = {er:.3e}")
     assert e <= 1e-5
+
+
+def test_multi_gpu_driver_host_staged_fallback():
+    """fdes_plan_accumulate_from (the sum of src/crystalMaker.cu:347-365 for a measurement whose configurations ran on two
+    plans): the peer-copy path and the host-staged fallback it takes when the runtime refuses a peer copy (forced here by
+    option peer_copy = 0, which also takes it between two plans of one device) give the single-plan image."""
+    hp, at = S.case_tiny(m=256, m3=4, nz=2, frPh=4, nat=100, tilt=True)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0)
+    ref = eng.build_measurements(hp, at, want_exitwave=True)
+    eng.close()
+    for peer in (1, 0):
+        ea, eb = fdes_amd.Engine(0, peer_copy=peer), fdes_amd.Engine(0)
+        pa, pb = ea.plan(hp, at), eb.plan(hp, at)
+        pa.want_exitwave(True)
+        pb.want_exitwave(True)
+        pa.begin_measurement(0)
+        pb.begin_measurement(0)
+        for j in (0, 1):
+            pa.run_config(0, j, 0.25)
+        for j in (2, 3):
+            pb.run_config(0, j, 0.25)
+        pb.sync()
+        pa.accumulate_from(pb)
+        ew = pa.get_exitwave()
+        pa.end_measurement(0)
+        img = pa.get_images()
+        e, e2 = relerr(img, ref["image"]), relerr(ew, ref["exitwave"][0, ..., 0] + 1j * ref["exitwave"][0, ..., 1])
+        print(f"[parity] accumulate_from peer_copy={peer}: image {e:.3e}, exit-wave sum {e2:.3e}")
+        assert e < 2e-6 and e2 < 2e-6
+        for q in (pa, pb):
+            q.close()
+        ea.close()
+        eb.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# batched potential chain of one-lane plans (engine.hip, batched_loop)
+# ------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kw", [dict(m=256, m3=11, nz=2, nat=200, tilt=True), dict(m=512, m3=7, nz=1, nat=300, zfrac=0.2),
+                                dict(m=1024, m3=9, nz=2, nat=300, mode=2), dict(m=800, m3=6, nz=2, nat=200, zfrac=0.3)])
+def test_batched_potential_chain_does_not_change_a_bit(oracle, kw):
+    """A single image (one configuration, one lane): the potential / transmission passes of several slice pairs as one
+    launch each (grid.z), the wave's passes one batch behind.  Same kernels, same operands: the exit wave is bit-identical
+    to the unbatched two-stream loop and to the single-stream loop for every batch size, odd slice counts, empty slices at
+    both ends (skip_empty 0 and 1), one and two species, a power-of-two and a mixed-radix grid; and equals the oracle."""
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    ref = oracle.wave(q, at, 0, 0, prec="f64")
+    for skip in (0, 1):
+        outs = {}
+        for label, opts in (("single stream", dict(split=0)), ("split", dict(split=1, batch=0)), ("batch 2", dict(batch=2)),
+                            ("batch 3", dict(batch=3)), ("batch 8", dict(batch=8)), ("default", dict())):
+            eng = fdes_amd.Engine(0, skip_empty=skip, **opts)
+            pl = eng.plan(hp, at)
+            assert pl.lanes() == 1 and pl.fft_backend() == 2
+            outs[label] = pl.tap_wave(0, 0)
+            pl.close()
+            eng.close()
+        check(outs["default"], ref, None, 1e-5, f"batched potential chain {kw} skip_empty={skip}")
+        for label, o in outs.items():
+            assert np.array_equal(o.view(np.uint64), outs["single stream"].view(np.uint64)), (label, kw, skip)
