@@ -186,10 +186,25 @@ std::recursive_mutex g_capture_mutex;
 // touching freed memory.
 std::mutex g_live_mutex;
 std::set<const void*> g_live_ctx, g_live_plan;
-bool live_ctx(const fdes_ctx* c) { std::lock_guard<std::mutex> g(g_live_mutex); return g_live_ctx.count(c) != 0; }
-bool live_plan(const fdes_plan* p) { std::lock_guard<std::mutex> g(g_live_mutex); return g_live_plan.count(p) != 0; }
+bool live_ctx(const fdes_ctx* c) { if (!c) return false; std::lock_guard<std::mutex> g(g_live_mutex); return g_live_ctx.count(c) != 0; }
+bool live_plan(const fdes_plan* p) { if (!p) return false; std::lock_guard<std::mutex> g(g_live_mutex); return g_live_plan.count(p) != 0; }
 std::once_flag g_atexit_once;
 void shutdown_all();
+// Destroyed handles are not handed back to the allocator at once: a stale handle (a late finaliser, a host bug) whose
+// address the allocator had given to a NEW context or plan would pass the registry check and hit the wrong object.  The
+// emptied shells (a few hundred bytes each; every GPU resource and vector is released before) wait in a graveyard of
+// 1024 entries, so an address is reused only after 1024 later destructions.
+template <class T> void bury(T* obj)
+{
+    static std::mutex m;
+    static std::vector<T*> graveyard;
+    static size_t next = 0;
+    std::lock_guard<std::mutex> g(m);
+    if (graveyard.size() < 1024) { graveyard.push_back(obj); return; }
+    delete graveyard[next];
+    graveyard[next] = obj;
+    next = (next + 1) % graveyard.size();
+}
 
 // run-time options of a lane are those of the context that owns the plan (the lane contexts are private copies made at
 // plan creation: only what shapes the allocation - fft, lanes, pass_threads - is frozen there)
@@ -958,7 +973,10 @@ int fdes_destroy(fdes_ctx* c)
     for (auto& kv : c->fft_cache) { kv.second->destroy(); delete kv.second; }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     { std::lock_guard<std::mutex> g(g_live_mutex); g_live_ctx.erase(c); }
-    delete c;
+    c->fft_cache.clear();
+    c->plans.clear();
+    c->stream = nullptr;
+    bury(c);
     return FDES_OK;
 }
 
@@ -975,7 +993,7 @@ int fdes_set_progress(fdes_ctx* c, fdes_progress_fn fn, void* user, int min_inte
 
 int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
 {
-    if (!c || !key) return FDES_EINVAL;
+    if (!live_ctx(c) || !key) return FDES_EINVAL;
     if (!std::strcmp(key, "fft")) { if (value < 0 || value > 2) return FDES_EINVAL; c->opt_fft = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
@@ -1031,13 +1049,17 @@ int fdes_plan_destroy(fdes_plan* pl)
     for (void* q : {(void*)pl->bA, (void*)pl->bB, (void*)pl->bCC, (void*)pl->bE[0], (void*)pl->bE[1]}) if (q) (void)hipFree(q);
     for (hipEvent_t e : {pl->evReady[0], pl->evReady[1], pl->evDone[0], pl->evDone[1]}) if (e) (void)hipEventDestroy(e);
     fdes_params_release(&pl->p0);
-    delete pl;
+    // release what the shell owns on the host; the shell itself goes to the graveyard (see bury())
+    pl->kz = {}; pl->lanes = {}; pl->lane_ctx = {}; pl->lane_ev = {}; pl->seg_h = {}; pl->pow_tabs = {}; pl->graphs = {}; pl->probe = {};
+    pl->evs = {}; pl->peer_host = {};
+    pl->ctx = nullptr;
+    bury(pl);
     return FDES_OK;
 }
 
 int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, fdes_plan** out)
 {
-    if (!c || !out) return FDES_EINVAL;
+    if (!live_ctx(c) || !out) return FDES_EINVAL;
     *out = nullptr;
     std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
     RC(check_params(c, p_in, a));
@@ -1277,7 +1299,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
 
 int fdes_plan_begin_measurement(fdes_plan* pl, int k)
 {
-    if (!pl || k < 0 || k >= pl->p.n3) return FDES_EINVAL;
+    if (!live_plan(pl) || k < 0 || k >= pl->p.n3) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, k_fill(pl->I, pl->m12, 0.f, 0.f, c->stream));
@@ -1288,7 +1310,7 @@ int fdes_plan_begin_measurement(fdes_plan* pl, int k)
 
 int fdes_plan_run_config(fdes_plan* pl, int k, int j, float weight)
 {
-    if (!pl || k < 0 || k >= pl->p.n3 || j < 0) return FDES_EINVAL;
+    if (!live_plan(pl) || k < 0 || k >= pl->p.n3 || j < 0) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     if (!pl->lanes.empty()) {
@@ -1322,7 +1344,7 @@ int fdes_plan_run_config(fdes_plan* pl, int k, int j, float weight)
 int fdes_plan_end_measurement(fdes_plan* pl, int k)
 {
     // addNoiseAndMtf, src/crystalMaker.cu:579-613
-    if (!pl || k < 0 || k >= pl->p.n3) return FDES_EINVAL;
+    if (!live_plan(pl) || k < 0 || k >= pl->p.n3) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     const fdes_params& p = pl->p;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1347,7 +1369,7 @@ int fdes_plan_end_measurement(fdes_plan* pl, int k)
 
 int fdes_plan_intensity_ptr(fdes_plan* pl, void** dev_ptr, size_t* bytes)
 {
-    if (!pl || !dev_ptr) return FDES_EINVAL;
+    if (!live_plan(pl) || !dev_ptr) return FDES_EINVAL;
     *dev_ptr = pl->I;
     if (bytes) *bytes = sizeof(float2) * pl->m12;
     return FDES_OK;
@@ -1355,7 +1377,7 @@ int fdes_plan_intensity_ptr(fdes_plan* pl, void** dev_ptr, size_t* bytes)
 
 int fdes_plan_copy_intensity(fdes_plan* pl, void* dev_buf, int to_plan)
 {
-    if (!pl || !dev_buf) return FDES_EINVAL;
+    if (!live_plan(pl) || !dev_buf) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     RC(fold_lanes(pl));
@@ -1368,7 +1390,7 @@ int fdes_plan_copy_intensity(fdes_plan* pl, void* dev_buf, int to_plan)
 
 int fdes_plan_copy_intensity_real(fdes_plan* pl, void* dev_buf, int to_plan)
 {
-    if (!pl || !dev_buf) return FDES_EINVAL;
+    if (!live_plan(pl) || !dev_buf) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     RC(fold_lanes(pl));
@@ -1381,7 +1403,7 @@ int fdes_plan_copy_intensity_real(fdes_plan* pl, void* dev_buf, int to_plan)
 
 int fdes_plan_images_ptr(fdes_plan* pl, void** dev_ptr, size_t* bytes)
 {
-    if (!pl || !dev_ptr) return FDES_EINVAL;
+    if (!live_plan(pl) || !dev_ptr) return FDES_EINVAL;
     *dev_ptr = pl->J;
     if (bytes) *bytes = sizeof(float) * (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3;
     return FDES_OK;
@@ -1389,7 +1411,7 @@ int fdes_plan_images_ptr(fdes_plan* pl, void** dev_ptr, size_t* bytes)
 
 int fdes_plan_sync(fdes_plan* pl)
 {
-    if (!pl) return FDES_EINVAL;
+    if (!live_plan(pl)) return FDES_EINVAL;
     HIPCHK(pl->ctx, hipSetDevice(pl->ctx->device));
     for (fdes_plan* l : pl->lanes) { if (l->vs) HIPCHK(pl->ctx, hipStreamSynchronize(l->vs)); HIPCHK(pl->ctx, hipStreamSynchronize(l->ctx->stream)); }
     if (pl->vs) HIPCHK(pl->ctx, hipStreamSynchronize(pl->vs));
@@ -1399,7 +1421,7 @@ int fdes_plan_sync(fdes_plan* pl)
 
 int fdes_plan_get_images(fdes_plan* pl, float* image)
 {
-    if (!pl || !image) return FDES_EINVAL;
+    if (!live_plan(pl) || !image) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(image, pl->J, sizeof(float) * (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3, hipMemcpyDeviceToHost, c->stream));
@@ -1412,14 +1434,14 @@ int fdes_grid_backend(int m1, int m2, int fft_option)
     if (m1 < 1 || m2 < 1) return FDES_EINVAL;
     return (fft_option != 1 && Fft2D::lds_supported(m1, m2)) ? 2 : 1;
 }
-int fdes_plan_fft_backend(const fdes_plan* pl) { return pl ? pl->fft->backend : FDES_EINVAL; }
-int fdes_plan_lanes(const fdes_plan* pl) { return pl ? (int)pl->lanes.size() + 1 : FDES_EINVAL; }
-int fdes_plan_num_slices(const fdes_plan* pl) { return pl ? pl->p.m3 : FDES_EINVAL; }
+int fdes_plan_fft_backend(const fdes_plan* pl) { return live_plan(pl) ? pl->fft->backend : FDES_EINVAL; }
+int fdes_plan_lanes(const fdes_plan* pl) { return live_plan(pl) ? (int)pl->lanes.size() + 1 : FDES_EINVAL; }
+int fdes_plan_num_slices(const fdes_plan* pl) { return live_plan(pl) ? pl->p.m3 : FDES_EINVAL; }
 int64_t fdes_plan_empty_queries(const fdes_plan* pl) { return pl ? (pl->top ? pl->top : pl)->empty_queries : 0; }
 
 int64_t fdes_plan_slices_done(const fdes_plan* pl)
 {
-    if (!pl) return 0;
+    if (!live_plan(pl)) return 0;
     int64_t n = pl->slices_done;
     for (const fdes_plan* l : pl->lanes) n += l->slices_done;
     return n;
@@ -1427,7 +1449,7 @@ int64_t fdes_plan_slices_done(const fdes_plan* pl)
 
 int fdes_plan_slice_loop_ms(fdes_plan* pl, double* total_ms, int64_t* slices)
 {
-    if (!pl) return FDES_EINVAL;
+    if (!live_plan(pl)) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1455,7 +1477,7 @@ int fdes_plan_slice_loop_ms(fdes_plan* pl, double* total_ms, int64_t* slices)
 
 int fdes_plan_probe_ms(fdes_plan* pl, double* total_ms, int64_t* launches)
 {
-    if (!pl) return FDES_EINVAL;
+    if (!live_plan(pl)) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1481,14 +1503,14 @@ int fdes_plan_probe_ms(fdes_plan* pl, double* total_ms, int64_t* launches)
 
 int fdes_plan_want_exitwave(fdes_plan* pl, int on)
 {
-    if (!pl) return FDES_EINVAL;
+    if (!live_plan(pl)) return FDES_EINVAL;
     pl->want_ew = on != 0;
     return FDES_OK;
 }
 
 int fdes_plan_get_exitwave(fdes_plan* pl, float* ew)
 {
-    if (!pl || !ew || !pl->want_ew) return FDES_EINVAL;
+    if (!live_plan(pl) || !ew || !pl->want_ew) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     RC(fold_lanes(pl));
@@ -1504,7 +1526,7 @@ int fdes_plan_get_exitwave(fdes_plan* pl, float* ew)
 // caller may let src continue afterwards.
 int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src)
 {
-    if (!dst || !src || dst == src || dst->m12 != src->m12) return FDES_EINVAL;
+    if (!live_plan(dst) || !live_plan(src) || dst == src || dst->m12 != src->m12) return FDES_EINVAL;
     fdes_ctx *dc = dst->ctx, *sc = src->ctx;
     HIPCHK(sc, hipSetDevice(sc->device));
     RC(fold_lanes(src));
@@ -1556,7 +1578,7 @@ int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src)
 // (the reference leaves it uninitialised when ratio == 1, frPh == 0 and the last specimen tilt is zero).
 int fdes_plan_potential(fdes_plan* pl, int s_lo, int s_hi, float* potential)
 {
-    if (!pl || !potential) return FDES_EINVAL;
+    if (!live_plan(pl) || !potential) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     const float inv = 1.f / (float)pl->ratio;
@@ -1577,7 +1599,7 @@ int fdes_plan_original_slices(const fdes_plan* pl) { return pl ? (int)(((float)p
 
 int fdes_plan_tap_coords(fdes_plan* pl, int k, int j, float* xyz)
 {
-    if (!pl || !xyz || k >= pl->p.n3) return FDES_EINVAL;
+    if (!live_plan(pl) || !xyz || k >= pl->p.n3) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     const float* src = pl->xyzTO_d;
@@ -1593,7 +1615,7 @@ int fdes_plan_tap_coords(fdes_plan* pl, int k, int j, float* xyz)
 
 int fdes_plan_tap_potential(fdes_plan* pl, int k, int j, int s, float* V)
 {
-    if (!pl || !V || k < 0 || k >= pl->p.n3 || s < 0 || s >= pl->p.m3) return FDES_EINVAL;
+    if (!live_plan(pl) || !V || k < 0 || k >= pl->p.n3 || s < 0 || s >= pl->p.m3) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     RC(config_atoms(pl, k, j < 0 ? 0 : j));
@@ -1617,7 +1639,7 @@ int fdes_plan_tap_potential(fdes_plan* pl, int k, int j, int s, float* V)
 
 int fdes_plan_tap_wave(fdes_plan* pl, int k, int j, int nslices, float* psi)
 {
-    if (!pl || !psi || k < 0 || k >= pl->p.n3 || nslices < 0 || nslices > pl->p.m3) return FDES_EINVAL;
+    if (!live_plan(pl) || !psi || k < 0 || k >= pl->p.n3 || nslices < 0 || nslices > pl->p.m3) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     RC(incoming_wave(pl, k));
@@ -1630,7 +1652,7 @@ int fdes_plan_tap_wave(fdes_plan* pl, int k, int j, int nslices, float* psi)
 
 int fdes_plan_tap_propagator(fdes_plan* pl, float* P)
 {
-    if (!pl || !P) return FDES_EINVAL;
+    if (!live_plan(pl) || !P) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(P, pl->P, sizeof(float2) * pl->m12, hipMemcpyDeviceToHost, c->stream));
@@ -1640,7 +1662,7 @@ int fdes_plan_tap_propagator(fdes_plan* pl, float* P)
 
 int fdes_plan_propagate_dev(fdes_plan* pl, void* psi_dev, const void* t_dev, int batch, int t_per_wave)
 {
-    if (!pl || !psi_dev || !t_dev || batch < 1) return FDES_EINVAL;
+    if (!live_plan(pl) || !psi_dev || !t_dev || batch < 1) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     if (pl->fused) {
@@ -1794,7 +1816,7 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
 
 int fdes_build_measurements(fdes_ctx* c, const fdes_params* p, const fdes_atoms* a, float* image, float* potential, float* exitwave)
 {
-    if (!c || !image) return FDES_EINVAL;
+    if (!live_ctx(c) || !image) return FDES_EINVAL;
     fdes_plan* pl = nullptr;
     RC(fdes_plan_create(c, p, a, &pl));
     pl->want_ew = exitwave != nullptr;

@@ -260,3 +260,30 @@ def test_batched_potential_chain_does_not_change_a_bit(oracle, kw):
         check(outs["default"], ref, None, 1e-5, f"batched potential chain {kw} skip_empty={skip}")
         for label, o in outs.items():
             assert np.array_equal(o.view(np.uint64), outs["single stream"].view(np.uint64)), (label, kw, skip)
+
+
+def test_stale_handles_are_refused_everywhere():
+    """Every plan entry point checks its handle against the registry of live objects, and a destroyed object's address is
+    not reused at once (graveyard of 1024 shells): a stale handle - a late finaliser, a host bug - gets FDES_EINVAL (-1)
+    instead of reaching a newer plan that happens to live at the same address."""
+    import ctypes as C
+    hp, at = S.case_tiny(m=64, m3=2, nz=1, nat=10)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0)
+    lib = eng.lib
+    pl = eng.plan(hp, at)
+    stale = C.c_void_p(pl.h.value)
+    pl.close()
+    newer = [eng.plan(hp, at) for _ in range(4)]          # would reuse the address without the graveyard
+    assert all(q.h.value != stale.value for q in newer)
+    img = np.zeros((1, hp.c.n2, hp.c.n1), np.float32)
+    assert lib.fdes_plan_run_config(stale, 0, 0, 1.0) == -1
+    assert lib.fdes_plan_begin_measurement(stale, 0) == -1
+    assert lib.fdes_plan_get_images(stale, img.ctypes.data_as(C.POINTER(C.c_float))) == -1
+    assert lib.fdes_plan_sync(stale) == -1 and lib.fdes_plan_destroy(stale) == -1
+    assert lib.fdes_plan_fft_backend(stale) == -1 and lib.fdes_plan_lanes(stale) == -1
+    for q in newer:
+        q.close()
+    ctx_stale = C.c_void_p(eng.h.value)
+    eng.close()
+    assert lib.fdes_set_option(ctx_stale, b"seed", 3) == -1 and lib.fdes_destroy(ctx_stale) == -1
