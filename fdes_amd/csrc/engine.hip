@@ -1729,7 +1729,7 @@ int fdes_fft2d_host(fdes_ctx* c, float* data, int m1, int m2, int inverse, int b
 // (do concurrent kernels overlap their memory and compute phases?).
 int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t, int iters, int streams, double* us)
 {
-    if (!c || !us || iters < 1 || streams < 1 || streams > 8 || !lds_fft_supported_len(n)) return FDES_EINVAL;
+    if (!c || !us || iters < 1 || streams < 1 || streams > 8 || !(lds_fft_supported_len(n) || gen_pass_supported_len(n))) return FDES_EINVAL;
     // passes whose operands this hook does not provide (atom records, second output grid, species loop) are refused:
     // launching them on the scratch arguments would write through null pointers
     if (mid == MID_ATOMS || mid == MID_GTABN) { c->err = "bench_pass: pass needs operands the hook does not provide"; return FDES_EINVAL; }

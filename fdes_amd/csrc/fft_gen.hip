@@ -182,7 +182,7 @@ __device__ __forceinline__ bool gen_outside(int i1, int i2, float md) { return (
 
 // EPT: elements a thread owns (element e = tid + 512 i of the R x N tile, row-major)
 template <int EPT, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(kGenThreads, (EPT <= 8 ? 4 : 2)) void k_gpass(PassArgs A, GenFac F) // EPT <= 8 (rows up to 1024 points): two workgroups per CU
+__global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 2)) void k_gpass(PassArgs A, GenFac F) // EPT <= 8 (rows up to 1024 points): two workgroups per CU (the species loop of MID_GTABN needs more than 128 registers)
 {
     extern __shared__ cf glds[];
     const int N = F.n, R = F.rows, tid = threadIdx.x;
@@ -314,23 +314,32 @@ __global__ __launch_bounds__(kGenThreads, (EPT <= 8 ? 4 : 2)) void k_gpass(PassA
                     }
                 }
             }
-        } else {
+        } else if constexpr (MID != MID_MULPSI) {
             load_tile(in0, cur, (A.skip_dead_loads & 1) != 0);
         }
         cf keep_b[(MID == MID_MULPSI) ? EPT : 1]; // second operand of the product, transformed, in registers
         if constexpr (MID == MID_MULPSI) {
-            // the second operand goes through the tile images first and waits in registers
-            cf* c2 = other; // `cur` holds the first operand
-            cf* o2 = twl + N; // third image behind the twiddle table
-            load_tile(in1, c2, (A.skip_dead_loads & 2) != 0);
-            __syncthreads();
-            if constexpr (PRE != XF_NONE) {
-                // ping-pong between `other` and the third image; `cur` is not touched
-                gen_fft(c2, o2, twl, F, PRE == XF_INV);
-            }
+            // Two tile images serve both operands (a third one would leave room for ONE workgroup per CU: measured, the pass
+            // then does not overlap with the other lanes' at all): the first operand is requested into registers, the
+            // second one goes through the images, is transformed and parked in registers, then the first one moves in.
+            cf areg[EPT];
+            const bool band0 = (A.skip_dead_loads & 1) != 0;
 #pragma unroll
             for (int i = 0; i < EPT; i++)
-                if (valid(i)) keep_b[i] = c2[er[i] * N + ec[i]];
+                if (valid(i)) {
+                    const bool dead = band0 && dead_index(iwc(ec[i], N), A.band);
+                    areg[i] = dead ? cf{0.f, 0.f} : in0[(unsigned)er[i] * pin + (unsigned)ec[i]];
+                }
+            load_tile(in1, cur, (A.skip_dead_loads & 2) != 0);
+            __syncthreads();
+            if constexpr (PRE != XF_NONE) gen_fft(cur, other, twl, F, PRE == XF_INV);
+#pragma unroll
+            for (int i = 0; i < EPT; i++)
+                if (valid(i)) keep_b[i] = cur[er[i] * N + ec[i]];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < EPT; i++)
+                if (valid(i)) cur[er[i] * N + ec[i]] = areg[i];
         }
         __syncthreads();
         if constexpr (PRE != XF_NONE) gen_fft(cur, other, twl, F, PRE == XF_INV);
@@ -432,8 +441,8 @@ template <int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaunch(const
 {
     static std::atomic<unsigned long long> attr_set{0};
     auto kern = k_gpass<EPT, PRE, MID, POST, ST>;
-    // two images of the tile + the twiddle table (+ a third image for the second operand of a product)
-    const size_t lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * ((MID == MID_MULPSI) ? 3 : 2) + (size_t)f.n) + 64;
+    // two images of the tile + the twiddle table
+    const size_t lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * 2 + (size_t)f.n) + 64;
     int dev = 0;
     {
         hipError_t e = hipGetDevice(&dev);
