@@ -265,6 +265,7 @@ def test_shipped_au309_example_through_the_cli(oracle, tmp_path):
     print("[parity] Au-309 CLI: fraction of pixels equal to rounding:", close.mean(), "mean", img.mean(), ref.mean())
     assert close.mean() > 0.97
     assert abs(img.mean() - ref.mean()) < 2e-3 * ref.mean()
+    print("[parity] Au-309 CLI: libhdf5 available, results.emd read back:", bool(fdes_amd.emd_available()))
     if fdes_amd.emd_available():
         hp2, at2 = fdes_amd.read_emd(tmp_path / "results.emd")
         assert hp2.c.n3 == 25 and at2.n == 309
