@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--extras", type=int, default=1,
                     help="rank 0, N = 1: also time BASELINE config 5 (4096^2 x 512 slices) and the propagation-unit micro-benchmark "
                          "(SURVEY 8d) so that they are driver-timed figures; reported under `extras`, never as the headline")
+    ap.add_argument("--hbm-cold", type=int, default=1,
+                    help="also time the roofline kernel with its operands in HBM only (8 buffer sets round-robin; roofline.hbm_cold)")
     ap.add_argument("--skip-empty", type=int, default=0,
                     help="1: slices without atoms only get the Fresnel step (engine default); 0 (bench default): every "
                          "slice runs the full potential/transmission/propagation sequence like the reference")
@@ -184,7 +186,7 @@ def main():
             kname, alg_bytes = f"rocFFT 2-D C2C {m}x{m} (row + column kernels)", 32.0 * px
         ach = alg_bytes / per_launch_s / 1e9
         traffic, stale = pmc_traffic(m) if fused else (None, False)
-        cold = hbm_cold_launch(m, local) if (fused and m in (2048, 4096)) else None
+        cold = hbm_cold_launch(m, local) if (fused and args.hbm_cold and m in (2048, 4096)) else None
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_stale": stale,
                 "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": int(fft_n),

@@ -11,16 +11,18 @@ export TMPDIR=/tmp
 cd /tmp
 Q=$GRAFT_REPO_ROOT
 [ -z "$Q" ] && Q=/root/repo
-B2048="python3 $Q/bench.py --steps 4 --warmup 1 --cpu-baseline 0 --extra-skip-run 0 --extras 0"
+B2048="python3 $Q/bench.py --steps 4 --warmup 1 --cpu-baseline 0 --extra-skip-run 0 --extras 0 --hbm-cold 0"
 B1024="python3 $Q/bench.py --size 1024 --slices 64 --steps 8 --warmup 2 --cpu-baseline 0 --extra-skip-run 0 --extras 0"
 C5="python3 $Q/tools/run_c5.py 2"
 echo "== kernel traces"
 rocprofv3 --kernel-trace --stats -d $O/kt2048 -o kt -- $B2048 > $O/kt2048.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/kt4096 -o kt -- $C5 > $O/kt4096.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/kt1024 -o kt -- $B1024 > $O/kt1024.log 2>&1
-for s in 2048 4096 1024; do python3 $Q/tools/rocpd_stats.py $(ls $O/kt$s/*.db $O/kt$s/*/*.db 2>/dev/null | head -1) > $O/${R}_kernel_stats_$s.csv; done
+B1000="python3 $Q/bench.py --size 1000 --slices 64 --steps 8 --warmup 2 --cpu-baseline 0 --extra-skip-run 0 --extras 0"
+rocprofv3 --kernel-trace --stats -d $O/kt1000 -o kt -- $B1000 > $O/kt1000.log 2>&1
+for s in 2048 4096 1024 1000; do python3 $Q/tools/rocpd_stats.py $(ls $O/kt$s/*.db $O/kt$s/*/*.db 2>/dev/null | head -1) > $O/${R}_kernel_stats_$s.csv; done
 echo "== PMC"
-P2048="python3 $Q/bench.py --steps 1 --warmup 0 --lanes 1 --slices 32 --cpu-baseline 0 --extra-skip-run 0 --extras 0"
+P2048="python3 $Q/bench.py --steps 1 --warmup 0 --lanes 1 --slices 32 --cpu-baseline 0 --extra-skip-run 0 --extras 0 --hbm-cold 0"
 P4096="python3 $Q/tools/run_c5.py 1 lanes=1 slices=16"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA"; do
