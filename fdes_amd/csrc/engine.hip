@@ -1176,9 +1176,11 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         if ((c->pass_threads == 64 || c->pass_threads == 65) && (wave_pass_supported_len(m1) || wave_pass_supported_len(m2))) pl->wg = c->pass_threads; // one wave per row where the row length has such a kernel
         else if (c->pass_threads == 512) pl->wg = 512;
         else if ((c->pass_threads == 1 || c->pass_threads == 513 || (c->pass_threads == 0 && small)) && m1 <= 2048 && m2 <= 2048) pl->wg = 1;
-        // 2048-point rows: one wave per row (fft_wave.hip: one LDS exchange per transform, no barrier inside it; headline
+        // 2048- and 1024-point rows: one wave per row (fft_wave.hip: one LDS exchange per transform, no barrier inside it; headline
         // +4 ... +6 % over 256 threads x 2 rows, A/B on one box); 4096-point rows: measured equal to 512 threads, which stay
-        else if (c->pass_threads == 0 && (m1 == 2048 || m2 == 2048) && m1 <= 2048 && m2 <= 2048) pl->wg = 64;
+        // (1024-point rows, round 3: the same transform with a radix-4 across the four lane quarters, +5 % at 1024^2 over one
+        // row per thread with two exchanges; shorter rows of a mixed grid fall back to one row per thread)
+        else if (c->pass_threads == 0 && (m1 == 2048 || m2 == 2048 || m1 == 1024 || m2 == 1024) && m1 <= 2048 && m2 <= 2048) pl->wg = 64;
         else pl->wg = ok256 ? 256 : 512;
         // (mixed grids, e.g. 1000 x 512: the rows per workgroup of one axis must divide the other axis)
         if (m2 % lds_fft_rows_per_block(m1, pl->wg) != 0 || m1 % lds_fft_rows_per_block(m2, pl->wg) != 0) pl->wg = pl->fft->wg;
@@ -1204,10 +1206,10 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // against 27.4 k slice-propagations/s, 512^2 x 32 27.6 k against 23.4 k, 1024^2 x 32 17.6 k against 19.8 k)
         pl->split = c->split > 0 || (c->split < 0 && plan_lanes(c, pl) == 1 && pl->m12 >= ((size_t)1 << 20));
         // batched potential chain: one-lane plans whose slices cannot fill the chip by themselves (up to 2^20 pixels; a
-        // power-of-two or mixed-radix grid with the rows-per-thread kernels, i.e. not the one-wave-per-row ones)
+        // any fused grid; not with the pipelined one-wave-per-row kernels, which take no batches)
         {
             int nb = 1;
-            if (plan_lanes(c, pl) == 1 && c->split != 0 && !wave_pass_supported_len(m1) && !wave_pass_supported_len(m2)) {
+            if (plan_lanes(c, pl) == 1 && c->split != 0 && c->pass_threads != 65) {
                 if (c->batch > 1) nb = c->batch;
                 else if (c->batch < 0) nb = pl->m12 <= ((size_t)1 << 18) ? 8 : (pl->m12 <= ((size_t)1 << 20) ? 4 : 1); // measured (tools/bench_single.py): 512^2 8 > 4 > 2; 1024^2 4 >= 2, 8 lower
             }

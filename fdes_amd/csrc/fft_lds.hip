@@ -788,7 +788,7 @@ bool lds_fft_supported_len(int n) { return n == 256 || n == 512 || n == 1024 || 
 int lds_fft_rows_per_block(int n, int wg)
 {
     if (gen_pass_supported_len(n)) return gen_pass_rows(n);
-    if (wg == 64 || wg == 65) return wave_pass_supported_len(n) ? 4 : 256 * 2 * 16 / n;
+    if (wg == 64 || wg == 65) return (wave_pass_supported_len(n) || n <= 1024) ? 4 : 256 * 2 * 16 / n; // shorter rows: one row per thread, four rows per workgroup
     return wg == 1 ? 4 : (wg == 256 ? 256 * 2 : 512 * 2) * 16 / n;
 }
 
@@ -821,7 +821,7 @@ hipError_t lds_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
     if (gen_pass_supported_len(n)) return gen_pass(n, pre, mid, post, st_t, a, st);
     if (a.wg == 64 || a.wg == 65) {
         if (wave_pass_supported_len(n)) return wave_pass(n, pre, mid, post, st_t, a, st);
-        a.wg = 256; // shorter rows: two rows per thread
+        a.wg = n <= 1024 ? 1 : 256; // rows without such a kernel: one row per thread up to 1024 points, else two rows per thread
     }
     switch (n) {
     case 256: return dispatch_wg<256>(pre, mid, post, st_t, a, st);

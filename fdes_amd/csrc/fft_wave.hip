@@ -1,4 +1,4 @@
-// fft_wave.hip — LDS row-pass kernels, ONE WAVE PER ROW (gfx950), for 2048- and 4096-point rows.
+// fft_wave.hip — LDS row-pass kernels, ONE WAVE PER ROW (gfx950), for 1024-, 2048- and 4096-point rows.
 //
 // The passes of fft_lds.hip give a row to T = N/16 threads (two or four waves above 1024 points): every row FFT is three
 // radix stages with TWO exchanges through LDS and an s_barrier around each.  Here a row belongs to one wave, P = N/64
@@ -6,8 +6,10 @@
 //   lane t holds x[t + 64 l], l < P                                    (coalesced 512-byte loads, as before)
 //   S1  radix-P butterfly over the registers            Y[t][k1] = sum_l x[t + 64 l] W_P^(l k1)
 //   S2  twiddle                                         Y[t][k1] *= W_N^(t k1)
-//   S3  (P = 32 only) radix-2 across the two lane halves (t = t1 + 32 t0) by v_permlane32_swap_b32:
+//   S3  (P = 32) radix-2 across the two lane halves (t = t1 + 32 t0) by v_permlane32_swap_b32:
 //                                                       Z[t1][k1][b] = W_64^(t1 b) (Y[t1][k1] + (-1)^b Y[t1 + 32][k1])
+//       (P = 16) radix-4 across the four lane quarters (t = t1 + 16 t0) by v_permlane32_swap_b32 + v_permlane16_swap_b32:
+//                                                       Z[t1][k1][b] = W_64^(t1 b) sum_t0 Y[t1 + 16 t0][k1] W_4^(t0 b)
 //   S4  ONE exchange through this wave's own LDS region (no barrier: a wave's LDS instructions execute in order)
 //   S5  radix-P butterfly over the registers (index t1 resp. t)
 // and the result lands as register l of lane t = X[t + 64 l], the input pattern again, so FFT -> point-wise -> inverse
@@ -112,7 +114,8 @@ template <bool INV> __device__ __forceinline__ void r64(cf (&a)[64])
 }
 template <int P, bool INV> __device__ __forceinline__ void rP(cf (&a)[P])
 {
-    if constexpr (P == 32) r32<INV>(a);
+    if constexpr (P == 16) r16<INV>(a);
+    else if constexpr (P == 32) r32<INV>(a);
     else r64<INV>(a);
 }
 
@@ -124,18 +127,18 @@ template <int N> struct WaveGeo {
     static constexpr int P = N / 64;
     static constexpr int R = 4;
     static constexpr int THR = 64 * R;
-    static constexpr int XROW = P * 65;    // a multiple of 32 for P = 32, 64
-    static constexpr int ROWP = XROW + 8;
+    static constexpr int XROW = P * 65;
+    static constexpr int ROWP = ((XROW + 31) / 32) * 32 + 8;
     static constexpr int NB = P / 8;       // twiddle k = NB a + b
     static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)ROWP * R + 64;
-    static_assert(XROW % 32 == 0 && XROW >= N, "region layout");
+    static_assert(XROW >= N && ROWP % 32 == 8, "region layout");
 };
 
 // base powers of the stage twiddle w = W_N^t of lane t, and (P = 32) the radix-2 twiddle W_64^(t mod 32)
 template <int P> struct TwWave {
     cf lo[P / 8 - 1]; // w^b, b = 1 .. NB - 1
     cf hi[7];         // w^(NB a), a = 1 .. 7
-    cf w64;
+    cf w64[3];        // P = 32: [0] = W_64^(t1); P = 16: W_64^(t1 b), b = 1, 2, 3
 };
 // W_N^(t m) from the table tw0[k * (N/16) + t'] = W_N^(t' k) (k < 16, t' < N/16): m = k s with s a power of two, t' = s t
 __host__ __device__ constexpr int tw_step(int m) { int s = 1; while (m / s >= 16) s *= 2; return s; }
@@ -151,7 +154,11 @@ template <int N> __device__ __forceinline__ void tw_load(TwWave<N / 64>& tw, con
     for (int b = 1; b < NB; b++) tw.lo[b - 1] = tw_lookup<N>(tw0, b, t);
 #pragma unroll
     for (int a = 1; a < 8; a++) tw.hi[a - 1] = tw_lookup<N>(tw0, NB * a, t);
-    if constexpr (P == 32) tw.w64 = tw_lookup<N>(tw0, 32, t & 31); // W_64^(t1) = W_2048^(32 t1)
+    if constexpr (P == 32) tw.w64[0] = tw_lookup<N>(tw0, 32, t & 31); // W_64^(t1) = W_2048^(32 t1)
+    if constexpr (P == 16) {                                          // W_64^(t1 b) = W_1024^(16 b t1)
+#pragma unroll
+        for (int b = 1; b < 4; b++) tw.w64[b - 1] = tw_lookup<N>(tw0, 16 * b, t & 15);
+    }
 }
 
 // makes a base twiddle opaque to the optimiser, so that the products built from it are rebuilt per transform instead of
@@ -188,7 +195,7 @@ __device__ __forceinline__ void wave_fft(cf (&a)[N / 64], cf* __restrict__ xr, c
     if constexpr (P == 32) {
         // S3: radix-2 over the lane halves.  v_permlane32_swap_b32 vdst, src swaps lanes 32-63 of vdst with lanes 0-31 of
         // src: afterwards a[c] holds the t0 = 0 value and a[c + 16] the t0 = 1 value of k1 = c + 16 h (h = this lane's half)
-        cf w = tw.w64;
+        cf w = tw.w64[0];
         tw_opaque(w);
 #pragma unroll
         for (int c = 0; c < 16; c++) {
@@ -206,6 +213,43 @@ __device__ __forceinline__ void wave_fft(cf (&a)[N / 64], cf* __restrict__ xr, c
             wr[c] = a[c];
             wr[c + 32] = a[c + 16];
         }
+    } else if constexpr (P == 16) {
+        // S3: radix-4 over the four lane quarters, t = t1 + 16 t0.  Two swap levels bring the four quarters' values of
+        // k1 = c + 4 t0 (c < 4; t0 = this lane's quarter) into registers a[c + 4 g], g = quarter:
+        //   v_permlane32_swap a[c], a[c + 8] (c < 8): lanes of half h keep k1 = c + 8 h, quarters (t0 & 1) + {0, 2};
+        //   v_permlane16_swap a[c + 8 q], a[c + 4 + 8 q] (c < 4): odd rows of vdst <-> even rows of src.
+        typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const u2_ sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[c].x), __float_as_uint(a[c + 8].x), false, false);
+            const u2_ sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[c].y), __float_as_uint(a[c + 8].y), false, false);
+            a[c] = cf{__uint_as_float(sx.x), __uint_as_float(sy.x)};
+            a[c + 8] = cf{__uint_as_float(sx.y), __uint_as_float(sy.y)};
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const u2_ sx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[c + 8 * q].x), __float_as_uint(a[c + 4 + 8 * q].x), false, false);
+                const u2_ sy = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[c + 8 * q].y), __float_as_uint(a[c + 4 + 8 * q].y), false, false);
+                a[c + 8 * q] = cf{__uint_as_float(sx.x), __uint_as_float(sy.x)};
+                a[c + 4 + 8 * q] = cf{__uint_as_float(sx.y), __uint_as_float(sy.y)};
+            }
+        cf w1 = tw.w64[0], w2 = tw.w64[1], w3 = tw.w64[2];
+        tw_opaque(w1); tw_opaque(w2); tw_opaque(w3);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            r4<INV>(a[c], a[c + 4], a[c + 8], a[c + 12]); // over the quarters g -> b
+            a[c + 4] = twmul_rt<INV>(a[c + 4], w1);
+            a[c + 8] = twmul_rt<INV>(a[c + 8], w2);
+            a[c + 12] = twmul_rt<INV>(a[c + 12], w3);
+        }
+        // S4: element (k1 = c + 4 t0, b, t1) goes to lane k1 + 16 b, register t1
+        cf* wr = xr + (t & 15) * 65 + 4 * (t >> 4);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) wr[c + 16 * b] = a[c + 4 * b];
     } else {
         cf* wr = xr + t * 65;
 #pragma unroll
@@ -424,7 +468,11 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     };
     const unsigned pin = A.pitch_in ? (unsigned)A.pitch_in : (unsigned)N;
     const unsigned ldt0 = A.pitch_out ? (unsigned)A.pitch_out : (unsigned)A.nrows;
-    cf* const out0 = reinterpret_cast<cf*>(A.out) + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0);
+    // batch of grids in one launch (grid.z, PassArgs::nbatch; not with PIPE): this workgroup's grid
+    const int bz = (int)blockIdx.z;
+    const size_t zoff_in = (A.nbatch > 1) ? (size_t)(A.use_zin ? A.zin[bz] : bz) * A.bstride_in0 : (size_t)0;
+    const size_t zoff_out = (A.nbatch > 1) ? (size_t)bz * A.bstride_out : (size_t)0;
+    cf* const out0 = reinterpret_cast<cf*>(A.out) + zoff_out + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0);
 
     // operands requested ahead: the row(s) of in0 / in1 and the filter values of this wave's row in the (next) group
     constexpr bool LOADS_ROW = (MID != MID_ATOMS && MID != MID_GTABN);
@@ -446,7 +494,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
                 for (int l = 0; l < P; l++) acc_load32(gn[l], (unsigned)(t + 64 * l) * 4u, A.gtab + rb);
             }
         } else {
-            if constexpr (LOADS_ROW) wload_row<N>(an, reinterpret_cast<const cf*>(A.in0) + rb, t, (A.skip_dead_loads & 1) != 0);
+            if constexpr (LOADS_ROW) wload_row<N>(an, reinterpret_cast<const cf*>(A.in0) + rb + zoff_in, t, (A.skip_dead_loads & 1) != 0);
             if constexpr (PRE_B) wload_row<N>(bn, reinterpret_cast<const cf*>(A.in1) + rb, t, (A.skip_dead_loads & 2) != 0);
             if constexpr (MID == MID_GTAB) {
 #pragma unroll
@@ -486,7 +534,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     const int row0 = row0_of(vb);
     const int grow = row0 + w;
     const size_t rbase = (size_t)grow * pin; // wave-uniform
-    const cf* __restrict__ in0 = A.in0 ? reinterpret_cast<const cf*>(A.in0) + rbase : nullptr;
+    const cf* __restrict__ in0 = A.in0 ? reinterpret_cast<const cf*>(A.in0) + rbase + zoff_in : nullptr;
     const cf* __restrict__ in1 = A.in1 ? reinterpret_cast<const cf*>(A.in1) + rbase : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + rbase : nullptr;
 
@@ -557,7 +605,8 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
             int plo[2] = {0, 0}, phi[2] = {0, 0};
 #pragma unroll
             for (int comp = 0; comp < 2; comp++) {
-                const int q = (comp ? A.q1 : A.q0) < 0 ? -1 : (comp ? A.q1 : A.q0) + (int)blockIdx.y;
+                const int qb = (A.nbatch > 1) ? (comp ? A.zq1[bz] : A.zq0[bz]) : (comp ? A.q1 : A.q0);
+                const int q = qb < 0 ? -1 : qb + (int)blockIdx.y;
                 if (q >= 0) {
                     const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
                     plo[comp] = rs[rlo];
@@ -704,14 +753,14 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
         wtransmission(a, A.scale);
         __syncthreads(); // every wave has read the staged tile before the regions are exchange buffers again
         wxform<N, POST>(a, xr, t, tw);
-        store_row(a, reinterpret_cast<cf*>(A.out2));
+        store_row(a, reinterpret_cast<cf*>(A.out2) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_out2 : (size_t)0));
     }
     if constexpr (PIPE && (STORE_T || MID == MID_ATOMS)) __syncthreads(); // the staged tile has been read: the regions are free for the next group
     } while (PIPE && (vb += vstride) < nvirt);
 }
 
 template <int N, int PRE, int MID, int POST, bool STORE_T, bool PIPE>
-__global__ __launch_bounds__(WaveGeo<N>::THR, ((N <= 2048 && !PIPE) ? 2 : 1)) void k_wpass(PassArgs A)
+__global__ __launch_bounds__(WaveGeo<N>::THR, (N <= 1024 ? (MID == MID_GTABN ? 2 : 4) : ((N <= 2048 && !PIPE) ? 2 : 1))) void k_wpass(PassArgs A)
 {
     extern __shared__ cf wlds[];
     wpass_body<N, PRE, MID, POST, STORE_T, PIPE>(A, wlds);
@@ -746,6 +795,8 @@ template <int N, int PRE, int MID, int POST, bool ST, bool PIPE> hipError_t wlau
         else w.live_rows_only = 0; // everything is live
     }
     const int ny = (MID == MID_ATOMS) ? (a.nspecies > 0 ? a.nspecies : 1) : 1;
+    if (a.nbatch > 16 || (PIPE && a.nbatch > 1)) return hipErrorInvalidValue;
+    const int nz = a.nbatch > 1 ? a.nbatch : 1; // grid.z = batch
     w.nvirt = 0;
     w.vb0 = 0;
     int grid = groups;
@@ -755,10 +806,10 @@ template <int N, int PRE, int MID, int POST, bool ST, bool PIPE> hipError_t wlau
     }
     if (a.ev_start && a.ev_stop) {
         w.ev_start = w.ev_stop = nullptr;
-        hipExtLaunchKernelGGL(kern, dim3(grid, ny), dim3(G_::THR), G_::LDS_BYTES, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w);
+        hipExtLaunchKernelGGL(kern, dim3(grid, ny, nz), dim3(G_::THR), G_::LDS_BYTES, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(grid, ny), dim3(G_::THR), G_::LDS_BYTES, st, w);
+    hipLaunchKernelGGL(kern, dim3(grid, ny, nz), dim3(G_::THR), G_::LDS_BYTES, st, w);
     return hipGetLastError();
 }
 
@@ -793,15 +844,15 @@ template <int N, bool PIPE> hipError_t wdispatch(int pre, int mid, int post, boo
 
 } // namespace
 
-bool wave_pass_supported_len(int n) { return n == 2048 || n == 4096; }
+bool wave_pass_supported_len(int n) { return n == 1024 || n == 2048 || n == 4096; }
 
 hipError_t wave_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs& a_in, hipStream_t st)
 {
     PassArgs a = a_in;
-    if (a.nbatch > 1) return hipErrorInvalidValue; // batches of grids: fft_lds.hip / fft_gen.hip only
     if (a.band > 0 && a.band_L != n / 3) a.skip_dead_stores = 0; // the kernels' column classes assume the band of a square grid
-    const bool pipe = a.wg == 65;
+    const bool pipe = a.wg == 65 && a.nbatch <= 1;
     switch (n) {
+    case 1024: return wdispatch<1024, false>(pre, mid, post, st_t, a, st); // (a pass over 1024 rows is one generation of workgroups: nothing to pipeline)
     case 2048: return pipe ? wdispatch<2048, true>(pre, mid, post, st_t, a, st) : wdispatch<2048, false>(pre, mid, post, st_t, a, st);
     case 4096: return pipe ? wdispatch<4096, true>(pre, mid, post, st_t, a, st) : wdispatch<4096, false>(pre, mid, post, st_t, a, st);
     default: return hipErrorInvalidValue;

@@ -78,11 +78,12 @@ def test_bench_launch_path_against_oracle_at_headline_size(oracle):
 # ------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("threads", [64, 65])
-@pytest.mark.parametrize("shape", [(2048, 2048), (4096, 4096), (2048, 4096), (1024, 2048)])
+@pytest.mark.parametrize("shape", [(2048, 2048), (4096, 4096), (2048, 4096), (1024, 2048), (1024, 1024), (512, 1024)])
 def test_wave_fft_against_numpy(shape, threads):
     """The row FFT with one wave per row (radix-32 / radix-64 butterflies over the registers, one LDS exchange, the
-    radix-2 across lane halves by v_permlane32_swap at 2048 points) as a 2-D transform against numpy; 1024-point rows
-    fall back to the two-rows-per-thread kernels."""
+    radix-2 across lane halves by v_permlane32_swap at 2048 points, the radix-4 across lane quarters by v_permlane32_swap +
+    v_permlane16_swap at 1024 points) as a 2-D transform against numpy; 512-point rows fall back to the two-rows-per-thread
+    kernels."""
     eng = fdes_amd.Engine(0, pass_threads=threads)
     rng = np.random.default_rng(11)
     f = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
@@ -97,13 +98,13 @@ def test_wave_fft_against_numpy(shape, threads):
 
 
 @pytest.mark.parametrize("threads", [64, 65])
-@pytest.mark.parametrize("m,nz,stagger", [(2048, 1, 0), (2048, 2, 16), (4096, 1, 0), (4096, 2, 8)])
+@pytest.mark.parametrize("m,nz,stagger", [(2048, 1, 0), (2048, 2, 16), (4096, 1, 0), (4096, 2, 8), (1024, 1, 0), (1024, 3, 0)])
 def test_wave_passes_slice_loop(oracle, m, nz, stagger, threads):
     """Every pass of the slice loop on the one-wave-per-row kernels (P1' atoms, P2 with one and two species, the two-slice
     P3, P4, P5, P6, enter / leave), with and without the staggered start: exit wave after an odd number of slices and
     the potential of both members of a pair against the float64 oracle.  phaseGrating src/crystalMaker.cu:507-536,
     forwardPropagation src/multisliceSimulation.cu:538-549."""
-    hp, at = S.case_tiny(m=m, m3=5 if m == 2048 else 3, nz=nz, nat=300, tilt=True, seed=41 + nz)
+    hp, at = S.case_tiny(m=m, m3=5 if m <= 2048 else 3, nz=nz, nat=300, tilt=True, seed=41 + nz)
     fdes_amd.consistent(hp)
     q, _ = oracle.sub_sliced(hp)
     eng = fdes_amd.Engine(0, pass_threads=threads, skip_empty=0, stagger=stagger)
@@ -250,7 +251,8 @@ def test_batched_potential_chain_does_not_change_a_bit(oracle, kw):
     for skip in (0, 1):
         outs = {}
         for label, opts in (("single stream", dict(split=0)), ("split", dict(split=1, batch=0)), ("batch 2", dict(batch=2)),
-                            ("batch 3", dict(batch=3)), ("batch 8", dict(batch=8)), ("default", dict())):
+                            ("batch 3", dict(batch=3)), ("batch 8", dict(batch=8)), ("default", dict()),
+                            ("one wave per row, batch 4", dict(pass_threads=64, batch=4))):
             eng = fdes_amd.Engine(0, skip_empty=skip, **opts)
             pl = eng.plan(hp, at)
             assert pl.lanes() == 1 and pl.fft_backend() == 2
@@ -259,7 +261,10 @@ def test_batched_potential_chain_does_not_change_a_bit(oracle, kw):
             eng.close()
         check(outs["default"], ref, None, 1e-5, f"batched potential chain {kw} skip_empty={skip}")
         for label, o in outs.items():
-            assert np.array_equal(o.view(np.uint64), outs["single stream"].view(np.uint64)), (label, kw, skip)
+            if label.startswith("one wave") and kw["m"] == 1024:   # other kernels: equal within rounding, not bit by bit
+                assert relerr(o, outs["single stream"]) < 2e-6, (label, kw, skip)
+            else:
+                assert np.array_equal(o.view(np.uint64), outs["single stream"].view(np.uint64)), (label, kw, skip)
 
 
 def test_stale_handles_are_refused_everywhere():

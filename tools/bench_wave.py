@@ -13,12 +13,12 @@ BAND = {4: 1, 6: 1, 5: 6, 12: 4}  # band-limit bookkeeping per pass as the engin
 for n in sizes:
     for name, key in PASSES.items():
         row = f"n={n:5d} {name:10s}"
-        for wg in ((256 if n <= 2048 else 512), 64, 65):
-            for stg in ((0,) if wg != 64 else (0, 8, 16)):
+        for wg in ((1 if n <= 1024 else (256 if n <= 2048 else 512)), 64) + ((65,) if n >= 2048 else ()):
+            for stg in ((0,) if (wg != 64 or n <= 1024) else (0, 8, 16)):
                 eng = fdes_amd.Engine(0, pass_threads=wg, stagger=stg, bench_band=BAND.get(key[1], 0),
-                                      bench_pitch=32 if n == 2048 else 64)
+                                      bench_pitch=0 if n <= 1024 else (32 if n == 2048 else 64))
                 res = []
-                for ns in (1, 2):
+                for ns in ((1, 2) if n > 1024 else (1, 2, 3)):
                     try:
                         res.append(f"{eng.bench_pass(n, key[0], key[1], key[2], key[3], 200, ns):6.2f}")
                     except Exception as e:
