@@ -1173,14 +1173,14 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // or two lanes; 4096-point rows keep 512 threads (256 would cut the transposed-store segments to 16 bytes)
         // up to 1024^2 a pass is as long as its slowest workgroup: one row per thread, four rows per workgroup
         const bool small = m1 <= 1024 && m2 <= 1024;
+        const bool wave_len = m1 == 2048 || m2 == 2048 || m1 == 1024 || m2 == 1024;
         if ((c->pass_threads == 64 || c->pass_threads == 65) && (wave_pass_supported_len(m1) || wave_pass_supported_len(m2))) pl->wg = c->pass_threads; // one wave per row where the row length has such a kernel
         else if (c->pass_threads == 512) pl->wg = 512;
-        else if ((c->pass_threads == 1 || c->pass_threads == 513 || (c->pass_threads == 0 && small)) && m1 <= 2048 && m2 <= 2048) pl->wg = 1;
         // 2048- and 1024-point rows: one wave per row (fft_wave.hip: one LDS exchange per transform, no barrier inside it; headline
-        // +4 ... +6 % over 256 threads x 2 rows, A/B on one box); 4096-point rows: measured equal to 512 threads, which stay
-        // (1024-point rows, round 3: the same transform with a radix-4 across the four lane quarters, +5 % at 1024^2 over one
-        // row per thread with two exchanges; shorter rows of a mixed grid fall back to one row per thread)
-        else if (c->pass_threads == 0 && (m1 == 2048 || m2 == 2048 || m1 == 1024 || m2 == 1024) && m1 <= 2048 && m2 <= 2048) pl->wg = 64;
+        // +4 ... +6 % over 256 threads x 2 rows, 1024^2 +5 % over one row per thread, A/B on one box; shorter rows of a mixed
+        // grid fall back to one row per thread); 4096-point rows: measured equal to 512 threads, which stay
+        else if (c->pass_threads == 0 && wave_len && m1 <= 2048 && m2 <= 2048) pl->wg = 64;
+        else if ((c->pass_threads == 1 || c->pass_threads == 513 || (c->pass_threads == 0 && small)) && m1 <= 2048 && m2 <= 2048) pl->wg = 1;
         else pl->wg = ok256 ? 256 : 512;
         // (mixed grids, e.g. 1000 x 512: the rows per workgroup of one axis must divide the other axis)
         if (m2 % lds_fft_rows_per_block(m1, pl->wg) != 0 || m1 % lds_fft_rows_per_block(m2, pl->wg) != 0) pl->wg = pl->fft->wg;
