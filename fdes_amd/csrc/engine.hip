@@ -1209,7 +1209,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // any fused grid; not with the pipelined one-wave-per-row kernels, which take no batches)
         {
             int nb = 1;
-            if (plan_lanes(c, pl) == 1 && c->split != 0 && c->pass_threads != 65) {
+            if ((plan_lanes(c, pl) == 1 || c->batch > 1) && c->split != 0 && c->pass_threads != 65) { // (an explicit batch also applies to the lanes of a multi-configuration plan: measured)
                 if (c->batch > 1) nb = c->batch;
                 else if (c->batch < 0) nb = pl->m12 <= ((size_t)1 << 18) ? 8 : (pl->m12 <= ((size_t)1 << 20) ? 4 : 1); // measured (tools/bench_single.py): 512^2 8 > 4 > 2; 1024^2 4 >= 2, 8 lower
             }
@@ -1278,7 +1278,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             PLCHK(create_ctx(&lc, c->device, nlanes >= 3 ? (l <= 2 ? l : 0) : 0));
             lc->is_lane_ctx = true;
             // frozen here: fft, lanes, pass_threads (they shape the lane plan); the others are read through owner_ctx()
-            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad; lc->split = pl->split ? 1 : 0; lc->batch = 0;
+            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad; lc->split = pl->split ? 1 : 0; lc->batch = c->batch > 1 ? c->batch : 0;
             lc->share_PT = pl->PT; lc->share_GT = pl->GT; // read-only tables of the parent plan (built and synchronised above)
             pl->lane_ctx.push_back(lc);
             fdes_plan* lp = nullptr;
