@@ -200,3 +200,45 @@ def test_golden_tiny_images(oracle):
         img = oracle.build_measurements(hp, at, prec="f64")["image"]
         ref = g[name + "_f64"]
         assert np.linalg.norm(img - ref) / np.linalg.norm(ref) < 1e-10, name
+
+
+@pytest.mark.parametrize("kw", [dict(m=64, m3=5, nz=2, nat=60), dict(m=96, m3=4, nz=3, nat=80, rect=True, imPot=0.0),
+                                dict(m=60, m3=3, nz=1, nat=30, sub=2)])
+def test_slice_loop_against_an_independent_numpy_multislice(oracle, kw):
+    """The reference holds no wave function, so nothing reference-made pins the oracle's slice loop.  Second
+    opinion, written from the DEFINITIONS of the method (Kirkland's multislice as FDES configures it, SURVEY 8a / 8a') in
+    numpy float64 and sharing no line with oracle_core.c's forward_propagation / fresnel_propagator / zero_high_freq:
+        t_s   = exp(-Im V_s) exp(i Re V_s)                               (potential2Transmission)
+        BL[f] = F^-1[ M F[f] ],  M = [9 (i1^2 + i2^2) <= min(m1, m2)^2]   (radial 2/3 limit in index space, i = m/2 kept as +m/2)
+        psi  <- F^-1[ M exp(-i pi lambda d3 (kx^2 + ky^2)) F[ BL[t_s] psi ] ],  psi_0 = 1
+    on the potentials V_s the oracle's phaseGrating returns (those are checked independently above: Born integral, second
+    moment, band-limited Fourier sum).  Agreement of the exit wave to 1e-12 means the restatement has no transcription
+    error in the loop (operation order, normalisations 1/m12, band limit, propagator sign and scaling)."""
+    hp, at = S.case_tiny(**kw)
+    hp = oracle.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    c = q.c
+    m1, m2 = c.m1, c.m2
+    xyz = oracle.config_coords(q, at, 0, -1)
+    i1 = np.fft.fftfreq(m1) * m1
+    i2 = np.fft.fftfreq(m2) * m2
+    i1[m1 // 2] = m1 // 2  # iwCoordIp keeps index m/2 as +m/2 (include/coordArithmetic.h:32); it only matters squared
+    i2[m2 // 2] = m2 // 2
+    I1, I2 = np.meshgrid(i1, i2)
+    M = (9.0 * (I1 ** 2 + I2 ** 2) <= float(min(m1, m2)) ** 2)
+    kx, ky = I1 / (m1 * float(c.d1)), I2 / (m2 * float(c.d2))
+    pi_ref = float(np.float32(3.141592654))  # the reference's float constant (src/multisliceSimulation.cu:259), 2.8e-8 above pi
+    P = M * np.exp(-1j * pi_ref * float(c.lambda_) * float(c.d3) * (kx ** 2 + ky ** 2))
+    # the reference's two normalisations are the float32 number 1.f / (float)(m1 m2) (src/multisliceSimulation.cu:557-559, 599-602):
+    # exact on power-of-two grids, 6e-8 off otherwise; the float64 oracle keeps the reference's constant, so does this
+    nrm = float(np.float32(1.0) / np.float32(m1 * m2)) * (m1 * m2)
+    psi = np.ones((m2, m1), np.complex128)
+    for s in range(c.m3):
+        V = oracle.phase_grating(q, at, xyz, s, "f64")
+        t = np.exp(-V.imag) * np.exp(1j * V.real)
+        t = np.fft.ifft2(M * np.fft.fft2(t)) * nrm
+        psi = np.fft.ifft2(P * np.fft.fft2(t * psi)) * nrm
+    ref = oracle.wave(q, at, 0, 0, prec="f64")
+    err = np.linalg.norm(psi - ref) / np.linalg.norm(ref)
+    assert err < 1e-11, (kw, err)
+    assert np.abs(ref - 1).max() > 0.05   # a non-trivial wave
