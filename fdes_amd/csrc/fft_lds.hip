@@ -343,6 +343,14 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
     const int nvirt = A.nvirt > 0 ? A.nvirt : (int)gridDim.x;
     const int vb = (int)blockIdx.x + A.vb0;
     if (vb >= nvirt) return;
+    // Staggered start (PassArgs::stagger, units of 64 cycles; 0 = off): where two workgroups share a CU and a pass runs
+    // for several generations (4096-point rows with 256 threads), workgroups that start together stay in lockstep - both
+    // load, then both transform, then both store.  The second workgroup of a CU (taken as (vb / ncu) odd: workgroups are
+    // dealt breadth first; for speed only) starts late by about half a workgroup's life, once; later generations inherit
+    // the offset because a slot is refilled when its workgroup retires.
+    if (A.stagger > 0 && A.ncu > 0 && ((vb / A.ncu) & 1) && vb < 2 * A.ncu) {
+        for (int i = 0; i < A.stagger; i++) __builtin_amdgcn_s_sleep(1);
+    }
     // this thread's stage twiddles (they serve every transform of the pass and both rows); issued first so that their
     // latency hides behind the row loads.  Per row group: hoisted out of the walk loop they would stay live across the
     // whole body and cost more registers than the reload does time.

@@ -292,3 +292,29 @@ def test_stale_handles_are_refused_everywhere():
     ctx_stale = C.c_void_p(eng.h.value)
     eng.close()
     assert lib.fdes_set_option(ctx_stale, b"seed", 3) == -1 and lib.fdes_destroy(ctx_stale) == -1
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomised_parameter_sweep_round3_kernels(oracle, seed):
+    """Random draws over the parameter surface (mode incl. CBED and diffraction patterns, species, sub-slicing, odd and even
+    slice counts, empty slices, specimen and beam tilts, several measurements, frozen phonons, absorption, rectangular
+    grids) on the grids the round-3 kernels serve: 1024 and 2048 points (one wave per row; with lanes + graph or as a
+    single image on the batched chain), 320 / 640 / 800 / 1000 points (mixed radix) and their mixtures with power-of-two
+    lengths: images against the float64 oracle resp. the float32 oracle with the same Philox streams."""
+    rng = np.random.default_rng(3000 + seed)
+    m = int(rng.choice([1024, 2048, 320, 640, 800, 1000, 1024, 320]))
+    rect = bool(rng.integers(0, 3) == 0) and m in (1024, 2048, 640)
+    kw = dict(m=m, m3=int(rng.integers(1, 7)), nz=int(rng.integers(1, 4)), frPh=int(rng.choice([0, 0, 2, 3])),
+              mode=int(rng.choice([0, 0, 1, 2])), n3=int(rng.integers(1, 3)), seed=int(rng.integers(0, 1000)),
+              tilt=bool(rng.integers(0, 2)), beam_tilt=bool(rng.integers(0, 2)), imPot=float(rng.choice([0.0, 0.05, 0.2])),
+              rect=rect, nat=int(rng.integers(1, 200)), sub=int(rng.integers(1, 3)), zfrac=float(rng.choice([0.5, 0.3, 0.15])))
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0)
+    pl = eng.plan(hp, at)
+    assert pl.fft_backend() == 2
+    pl.close()
+    out = eng.build_measurements(hp, at)["image"]
+    eng.close()
+    ref = oracle.build_measurements(hp, at, prec="f64" if kw["frPh"] == 0 else "f32")["image"]
+    check(out, ref, None, 2e-5, f"round-3 sweep {seed}: {kw}")
