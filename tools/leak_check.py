@@ -2,10 +2,15 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import torch, fdes_amd
 from tests import specimens as S
-hp, at = S.case_tiny(m=256, m3=6, nz=2, frPh=2, n3=2, tilt=True, zfrac=0.3)
-fdes_amd.consistent(hp)
+"""Device-memory leak check: plans of every slice-loop flavour (lanes + graph, single image on the batched chain, mixed-radix
+grid, one-wave-per-row kernels) created, run and destroyed 25 times; free memory must come back.  Run on the GPU box."""
+import itertools
+CASES = [dict(m=256, m3=6, nz=2, frPh=2, n3=2, tilt=True, zfrac=0.3), dict(m=1024, m3=5, nz=2, nat=100), dict(m=320, m3=4, nz=1, frPh=3),
+         dict(m=2048, m3=3, nz=1, frPh=2, nat=100), dict(m=72, m3=3, nz=2)]
 free0 = None
-for it in range(25):
+for it, kw in zip(range(25), itertools.cycle(CASES)):
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
     eng = fdes_amd.Engine(0)
     out = eng.build_measurements(hp, at)
     pl = eng.plan(hp, at)
