@@ -130,7 +130,7 @@ template <int N> struct WaveGeo {
     static constexpr int XROW = P * 65;
     static constexpr int ROWP = ((XROW + 31) / 32) * 32 + 8;
     static constexpr int NB = P / 8;       // twiddle k = NB a + b
-    static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)ROWP * R + 64;
+    static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)ROWP * R + 64 + 512; // + the sine / cosine table (FDES_W_SINCOS_TAB)
     static_assert(XROW >= N && ROWP % 32 == 8, "region layout");
 };
 
@@ -382,6 +382,49 @@ template <int P, class F, class M> __device__ __forceinline__ void wexpiv_all(cf
     }
 }
 // t = exp(-imPot v) (cos v, sin v), v = a.x (potential2Transmission, src/multisliceSimulation.cu:41-52)
+// Sine / cosine through a 64-entry table of (cos, sin)(2 pi k / 64) in LDS (FDES_W_SINCOS_TAB; an experiment): x = k h + r,
+// |r| <= pi / 64, so cos r and sin r are two- and one-term polynomials (truncation 2e-11 / 2.4e-9) and the result is one
+// complex product with the table entry: about 15 vector instructions and one LDS read per value against 26 for
+// sincos_cw.  h is split into a 12-bit head (k h1 is exact for |k| < 4096, i.e. |x| < 400: the fast range) and a tail.
+#ifndef FDES_W_SINCOS_TAB
+#define FDES_W_SINCOS_TAB 0
+#endif
+__device__ __forceinline__ cf sincos_tab(float x, const cf* __restrict__ tab)
+{
+    const float kf = rintf(x * 10.1859163578813f); // 64 / (2 pi)
+    const int k = (int)kf & 63;
+    float r = fmaf(-kf, 0.09814453125f, x);          // 2 pi / 64 = 0.09817477042...: head with 12 significant bits
+    r = fmaf(-kf, 3.02391747e-05f, r);               // tail
+    const float r2 = r * r;
+    const float sr = r * fmaf(r2, -1.66666672e-1f, 1.0f);
+    const float cr = fmaf(r2, fmaf(r2, 4.16666679e-2f, -0.5f), 1.0f);
+    const cf t = tab[k];
+    return cf{t.x * cr - t.y * sr, t.y * cr + t.x * sr};
+}
+template <int P> __device__ __forceinline__ void wtransmission_tab(cf (&a)[P], const float impot, const cf* __restrict__ tab)
+{
+    float big = 0.f;
+#pragma unroll
+    for (int l = 0; l < P; l++) big = fmaxf(big, fabsf(a[l].x));
+    if (__builtin_expect(big <= 390.f, 1)) {
+#pragma unroll
+        for (int l = 0; l < P; l++) {
+            const float v = a[l].x;
+            cf t = sincos_tab(v, tab);
+            if (impot != 0.f) t = t * __expf(-(v * impot));
+            a[l] = t;
+        }
+    } else {
+#pragma unroll
+        for (int l = 0; l < P; l++) {
+            const float v = a[l].x;
+            float sn, cs;
+            sincos_wide(v, sn, cs);
+            const float e = (impot != 0.f) ? __expf(-(v * impot)) : 1.f;
+            a[l] = cf{e * cs, e * sn};
+        }
+    }
+}
 template <int P> __device__ __forceinline__ void wtransmission(cf (&a)[P], const float impot)
 {
     if (impot == 0.f) {
@@ -453,6 +496,15 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     }
     TwWave<P> tw;
     if constexpr (PRE != XF_NONE || POST != XF_NONE) tw_load<N>(tw, reinterpret_cast<const cf*>(A.tw0), t);
+    cf* const sctab = lds + (size_t)G_::ROWP * R + 8; // behind the row regions
+    if constexpr (MID == MID_EXPIV_PAIR && FDES_W_SINCOS_TAB) {
+        if (tid < 64) {
+            float sn, cs;
+            sincos_cw((float)tid * 0.0981747704246810f, sn, cs);
+            sctab[tid] = cf{cs, sn};
+        }
+        __syncthreads();
+    }
     // first row of the row group that virtual workgroup v owns: XCD-aware remap (fft_lds.hip: workgroups of one XCD own
     // consecutive row groups, so that the 32-byte segments of their transposed stores meet in that XCD's L2), then the
     // live groups only when the rows are frequencies
@@ -666,7 +718,8 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
             // waits as one float per pixel
 #pragma unroll
             for (int l = 0; l < P; l++) vim[l] = a[l].y;
-            wtransmission(a, A.scale);
+            if constexpr (FDES_W_SINCOS_TAB) wtransmission_tab(a, A.scale, sctab);
+            else wtransmission(a, A.scale);
         } else if constexpr (MID == MID_MASK) {
             const int Lr = live_cols(iwc(grow, A.nrows), A.mindim * A.mindim);
             const int tlo = Lr, thi = N - Lr;
@@ -750,7 +803,8 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     if constexpr (MID == MID_EXPIV_PAIR) {
 #pragma unroll
         for (int l = 0; l < P; l++) a[l] = cf{vim[l], 0.f};
-        wtransmission(a, A.scale);
+        if constexpr (FDES_W_SINCOS_TAB) wtransmission_tab(a, A.scale, sctab);
+        else wtransmission(a, A.scale);
         __syncthreads(); // every wave has read the staged tile before the regions are exchange buffers again
         wxform<N, POST>(a, xr, t, tw);
         store_row(a, reinterpret_cast<cf*>(A.out2) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_out2 : (size_t)0));
