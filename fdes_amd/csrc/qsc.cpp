@@ -15,8 +15,10 @@
 //     A1_0 = astigmatism[A]*1e-9, A1_1 = angle[rad]*1e-9, mtf_d is never read (rwQsc.cu:943-1012).
 //   * atoms are shifted by -(max-min)/2 with min starting at 1 and max at 0 (rwQsc.cu:1041-1083).
 // Not carried over (returns FDES_EUNSUPPORTED with a message): `tds: yes` (QSTEM's Einstein
-// displacements at read time — FDES has its own frozen phonons), `Cube:` boxed mode, `.cssr`/`.dat`
-// cells, and unit cells with partial or shared site occupancy (QSTEM removes atoms with ran1()).
+// displacements at read time — FDES has its own frozen phonons), `Cube:` boxed mode, and unit
+// cells with partial or shared site occupancy (QSTEM removes atoms with ran1()).
+// `.cssr` and `.dat` cells are read the way the vendored readUnitCell reads them; the reference's
+// own readQsc ends the program for any cell file whose name holds no ".cfg" (rwQsc.cu:976-983).
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -208,6 +210,144 @@ int read_cfg_atoms(const char* file, int ncoord, std::vector<QAtom>& atoms)
     return FDES_OK;
 }
 
+// makeCellVectMuls, matrixlib.cpp:722-747.  The lattice parameters and angles are floats in
+// the reference (data_containers.h:161-162).  Kept as written there, including vby[1] =
+// by*cos(gamma) (not sin) for a non-orthogonal cell.
+void cell_vectors(Cell& cell, float a, float b, float c, float alpha, float beta, float gamma)
+{
+    const double d = 1.7453292519943e-2; // PI180, matrixlib.h:27
+    std::memset(cell.Mm, 0, sizeof(cell.Mm));
+    cell.ax = a;
+    cell.by = b;
+    cell.c = c;
+    cell.Mm[0][0] = a;
+    if (alpha == 90 && beta == 90 && gamma == 90) {
+        cell.Mm[1][1] = b;
+        cell.Mm[2][2] = c;
+        return;
+    }
+    const double ca = std::cos(alpha * d), cb = std::cos(beta * d), cg = std::cos(gamma * d), sg = std::sin(gamma * d);
+    cell.Mm[1][0] = b * cg;
+    cell.Mm[1][1] = b * cg;
+    cell.Mm[2][0] = c * cb;
+    cell.Mm[2][1] = c * (ca - cb * cg) / sg;
+    cell.Mm[2][2] = c * (std::sqrt(1 - ca * ca - cb * cb + 2 * ca * cb * cg) / sg);
+}
+
+// readCSSRCellParams, fileio_fftw3.cpp:785-815: "a b c" / "alpha beta gamma SPGR = 1 ..." /
+// atom count.  A missing "SPGR =" crashes the reference; here it is an error.
+int read_cssr_cell(const char* file, Cell& cell)
+{
+    ParFile f;
+    if (!f.open(file)) return fail(FDES_EIO, "could not open CSSR input file", file);
+    std::string l1, l2, l3;
+    if (!f.next_line(l1) || !f.next_line(l2) || !f.next_line(l3)) return fail(FDES_EINVAL, "CSSR header is incomplete", file);
+    char s1[64] = "", s2[64] = "", s3[64] = "";
+    std::sscanf(l1.c_str(), " %63s %63s %63s", s1, s2, s3);
+    const float a = (float)std::atof(s1), b = (float)std::atof(s2), c = (float)std::atof(s3);
+    s1[0] = s2[0] = s3[0] = '\0';
+    std::sscanf(l2.c_str(), " %63s %63s %63s", s1, s2, s3);
+    const float alpha = (float)std::atof(s1), beta = (float)std::atof(s2), gamma = (float)std::atof(s3);
+    cell_vectors(cell, a, b, c, alpha, beta, gamma);
+    const size_t sp = l2.find("SPGR =");
+    if (sp == std::string::npos) return fail(FDES_EINVAL, "no 'SPGR =' on the second line of", file);
+    if (std::atoi(l2.c_str() + sp + 6) != 1) return fail(FDES_EUNSUPPORTED, "cannot interpret a space group other than 1 in", file);
+    cell.ncoord = std::atoi(l3.c_str());
+    if (cell.ncoord < 1) return fail(FDES_EINVAL, "number of atoms in CSSR file not specified", file);
+    return FDES_OK;
+}
+
+// readNextCSSRAtom called ncoord times, fileio_fftw3.cpp:998-1052: four header lines, then
+// "index element x y z  c1..c8  dw" per atom.  The reference leaves dw uninitialised when the
+// line is short; here a short line is an error.
+int read_cssr_atoms(const char* file, int ncoord, std::vector<QAtom>& atoms)
+{
+    ParFile f;
+    if (!f.open(file)) return fail(FDES_EIO, "could not open CSSR input file", file);
+    std::string buf;
+    for (int i = 0; i < 4; i++)
+        if (!f.next_line(buf)) return fail(FDES_EINVAL, "CSSR header is incomplete", file);
+    atoms.assign((size_t)ncoord, QAtom{});
+    for (int i = ncoord - 1; i >= 0; i--) {
+        if (!f.next_line(buf)) return fail(FDES_EINVAL, "number of atoms does not agree with atoms in file", file);
+        int k[9];
+        char el[64] = "", s1[64] = "", s2[64] = "", s3[64] = "";
+        double dw = 0;
+        const int got = std::sscanf(buf.c_str(), "%d %63s %63s %63s %63s %d %d %d %d %d %d %d %d %lf", &k[0], el, s1, s2, s3, &k[1], &k[2],
+                                    &k[3], &k[4], &k[5], &k[6], &k[7], &k[8], &dw);
+        if (got != 14) return fail(FDES_EINVAL, "incomplete atom data line in", file);
+        QAtom& a = atoms[(size_t)i];
+        a.x = (float)std::atof(s1);
+        a.y = (float)std::atof(s2);
+        a.z = (float)std::atof(s3);
+        a.occ = 1.0f;
+        a.Znum = z_number(el);
+        a.dw = (float)dw;
+        if (a.Znum < 1 || a.Znum > 103) return fail(FDES_EINVAL, "bad atomic number in", file);
+    }
+    return FDES_OK;
+}
+
+// readDATCellParams, fileio_fftw3.cpp:666-713.  Kept: the titles are substring matches from the
+// current line on, wrapping once ("a =" is also found inside "alpha =", "beta =", "gamma ="),
+// and alpha and gamma are stored swapped (:703-705).  pos_after_gamma is the line after the one
+// the "gamma =" lookup of readNextDATAtom (:854) stops on, or the end of the file.
+int read_dat_cell(const char* file, Cell& cell)
+{
+    ParFile f;
+    if (!f.open(file)) return fail(FDES_EIO, "could not open DAT input file", file);
+    std::string r;
+    int ncoord = 0;
+    double a = 0, b = 0, c = 0, alpha = 90.0, beta = 90.0, gamma = 90.0;
+    if (f.find("Number of atoms =", r)) std::sscanf(r.c_str(), "%d", &ncoord);
+    if (f.find("a =", r)) std::sscanf(r.c_str(), "%lf", &a);
+    if (f.find("b =", r)) std::sscanf(r.c_str(), "%lf", &b);
+    if (f.find("c =", r)) std::sscanf(r.c_str(), "%lf", &c);
+    if (f.find("alpha =", r)) std::sscanf(r.c_str(), "%lf", &alpha);
+    if (f.find("beta =", r)) std::sscanf(r.c_str(), "%lf", &beta);
+    if (f.find("gamma =", r)) std::sscanf(r.c_str(), "%lf", &gamma);
+    if (!(a > 0) || !(b > 0) || !(c > 0)) return fail(FDES_EINVAL, "lattice parameters a, b, c not specified in", file);
+    cell_vectors(cell, (float)a, (float)b, (float)c, /*cAlpha=*/(float)gamma, (float)beta, /*cGamma=*/(float)alpha);
+    cell.ncoord = ncoord;
+    if (ncoord < 1) return fail(FDES_EINVAL, "number of atoms in DAT file not specified", file);
+    return FDES_OK;
+}
+
+// readNextDATAtom called ncoord times, fileio_fftw3.cpp:825-895: after the "gamma =" line, every
+// line whose first two characters name an element is an atom: "El x y z"; dw = 0.45*28/(2 Z).
+int read_dat_atoms(const char* file, int ncoord, std::vector<QAtom>& atoms)
+{
+    ParFile f;
+    if (!f.open(file)) return fail(FDES_EIO, "could not open DAT input file", file);
+    std::string buf;
+    f.find("gamma =", buf);
+    atoms.assign((size_t)ncoord, QAtom{});
+    for (int i = ncoord - 1; i >= 0; i--) {
+        int element = 0;
+        do {
+            if (!f.next_line(buf)) return fail(FDES_EINVAL, "number of atoms does not agree with atoms in file", file);
+            element = z_number(buf);
+        } while (element == 0);
+        const char* s = buf.c_str() + (buf.size() < 2 ? buf.size() : 2);
+        while (*s == ' ' || *s == '\t') s++;
+        double data[3] = {0, 0, 0};
+        for (int j = 0; j < 3; j++) {
+            if (!s) return fail(FDES_EINVAL, "incomplete atom data line in", file);
+            data[j] = std::atof(s);
+            s = strnext(s);
+        }
+        QAtom& a = atoms[(size_t)i];
+        a.Znum = element;
+        a.x = (float)data[0];
+        a.y = (float)data[1];
+        a.z = (float)data[2];
+        a.dw = (float)(0.45 * 28.0 / (2.0 * element));
+        a.occ = 1.0f;
+        if (a.Znum < 1 || a.Znum > 103) return fail(FDES_EINVAL, "bad atomic number in", file);
+    }
+    return FDES_OK;
+}
+
 // rotateVect, matrixlib.cpp:599-634 (rotation about x, then y, then z)
 void rotate(double* u, double px, double py, double pz)
 {
@@ -234,13 +374,22 @@ void rotate(double* u, double px, double py, double pz)
 int build_super_cell(const char* file, int ncx, int ncy, int ncz, float ctx, float cty, float ctz, float xOff, float yOff,
                      std::vector<QAtom>& atoms, Cell& cell)
 {
+    // format by file-name ending, fileio_fftw3.cpp:1340-1368 (.pdb and .xyz are refused there too)
     const size_t n = std::strlen(file);
-    if (n < 4 || std::strcmp(file + n - 4, ".cfg") != 0)
-        return fail(FDES_EUNSUPPORTED, "only .cfg unit cells are supported (no .cssr/.dat/.pdb/.xyz)", file);
-    int rc = read_cfg_cell(file, cell);
-    if (rc) return rc;
+    auto ends = [&](const char* e) { return n >= std::strlen(e) && std::strcmp(file + n - std::strlen(e), e) == 0; };
     std::vector<QAtom> uc;
-    rc = read_cfg_atoms(file, cell.ncoord, uc);
+    int rc;
+    if (ends(".cssr")) {
+        rc = read_cssr_cell(file, cell);
+        if (!rc) rc = read_cssr_atoms(file, cell.ncoord, uc);
+    } else if (ends(".cfg")) {
+        rc = read_cfg_cell(file, cell);
+        if (!rc) rc = read_cfg_atoms(file, cell.ncoord, uc);
+    } else if (ends(".dat")) {
+        rc = read_dat_cell(file, cell);
+        if (!rc) rc = read_dat_atoms(file, cell.ncoord, uc);
+    } else
+        return fail(FDES_EUNSUPPORTED, "cannot read anything else than .cssr, .cfg or .dat unit cells (no .pdb/.xyz)", file);
     if (rc) return rc;
     const int nc = cell.ncoord;
     if (ncx < 1 || ncy < 1 || ncz < 1 || (double)nc * ncx * ncy * ncz > 2.0e9) return fail(FDES_EINVAL, "bad NCELLX/Y/Z", nullptr);
@@ -400,15 +549,19 @@ extern "C" int fdes_read_qsc(const char* file, fdes_params* p, fdes_atoms* atoms
     if (cube[0] > 0 && cube[1] > 0 && cube[2] > 0) return fail(FDES_EUNSUPPORTED, "'Cube:' (boxed super cell) is not supported", file);
     if (q.find("tds:", r) && yes(r)) return fail(FDES_EUNSUPPORTED, "'tds: yes' is not supported; use frozen_phonons", file);
 
-    // atomPosFile: as given, with ".cfg" appended when it has no extension (rwQsc.cu:170-215; .cssr is not read
-    // here).  The reference resolves it against the working directory; the .qsc's own directory is tried next.
-    if (cellFile.find('.') == std::string::npos) cellFile += ".cfg";
-    std::string cellPath = cellFile;
-    if (!file_exists(cellPath)) {
-        std::string dir = file;
-        size_t slash = dir.find_last_of('/');
-        if (slash != std::string::npos && cellFile[0] != '/') cellPath = dir.substr(0, slash + 1) + cellFile;
-    }
+    // atomPosFile: as given; without an extension ".cssr" is tried first, then ".cfg" (rwQsc.cu:181-210).  The
+    // reference resolves it against the working directory; the .qsc's own directory is tried next.
+    auto resolve = [&](const std::string& name) {
+        std::string path = name;
+        if (!file_exists(path)) {
+            std::string dir = file;
+            size_t slash = dir.find_last_of('/');
+            if (slash != std::string::npos && name[0] != '/') path = dir.substr(0, slash + 1) + name;
+        }
+        return path;
+    };
+    if (cellFile.find('.') == std::string::npos) cellFile += file_exists(resolve(cellFile + ".cssr")) ? ".cssr" : ".cfg";
+    std::string cellPath = resolve(cellFile);
     float xOff = 0.f, yOff = 0.f;
     if (q.find("xOffset:", r)) std::sscanf(r.c_str(), "%g", &xOff);
     if (q.find("yOffset:", r)) std::sscanf(r.c_str(), "%g", &yOff);
@@ -502,9 +655,13 @@ extern "C" int fdes_read_qsc(const char* file, fdes_params* p, fdes_atoms* atoms
     p->ab.C3_0 = (float)(Cs * 1e-10);
     p->ab.C5_0 = (float)(C5 * 1e-3);
     {
+        // rwQsc.cu:973-992 cuts the names at ".cfg" and ends the program (EXIT_FAILURE, :981) when the name holds
+        // none, so a .cssr/.dat cell never gets past readQsc there; here those names are cut at their own ending.
         std::string mat = cellFile, name = cellFile;
         size_t dot = mat.find(".cfg");
-        if (dot == std::string::npos) return fail(FDES_EINVAL, "crystal file is not a .cfg", cellFile.c_str());
+        if (dot == std::string::npos) dot = mat.rfind(".cssr");
+        if (dot == std::string::npos) dot = mat.rfind(".dat");
+        if (dot == std::string::npos) return fail(FDES_EINVAL, "crystal file is not a .cfg, .cssr or .dat", cellFile.c_str());
         mat.resize(dot);
         char cellnum[64];
         std::snprintf(cellnum, sizeof(cellnum), "_CELL_%02d_%02d_%02d", ncx, ncy, ncz);

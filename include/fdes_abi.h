@@ -109,10 +109,11 @@ int fdes_write_emd(const char* file, const fdes_params* p, const fdes_atoms* ato
 /* readHdf5, src/rwHdf5.cu:1946-2570: parameters + atoms from an EMD configuration/result file.  `p` from
  * fdes_params_init (capacity >= image_size_z); call fdes_params_consistent afterwards.  flags: FDES_CNF_SKIP_ATOMS. */
 int fdes_read_emd(const char* file, fdes_params* p, fdes_atoms* atoms, int flags);
-/* readQsc, src/rwQsc.cu:8-1101 (+ qstem-libs readparam / .cfg cell reader / replicateUnitCell): a QSTEM
- * `.qsc` file and the `.cfg` unit cell it names -> parameters (n3 = 1) + the NCELL super cell.  `p` from
- * fdes_params_init; call fdes_params_consistent afterwards.  flags: FDES_CNF_SKIP_ATOMS.
- * FDES_EUNSUPPORTED for non-TEM modes, `tds: yes`, `Cube:` and partial/shared site occupancies. */
+/* readQsc, src/rwQsc.cu:8-1101 (+ qstem-libs readparam / readUnitCell / replicateUnitCell): a QSTEM
+ * `.qsc` file and the `.cfg` (or `.cssr` / `.dat`) unit cell it names -> parameters (n3 = 1) + the NCELL
+ * super cell.  `p` from fdes_params_init; call fdes_params_consistent afterwards.  flags: FDES_CNF_SKIP_ATOMS.
+ * FDES_EUNSUPPORTED for non-TEM modes, `tds: yes`, `Cube:`, `.pdb`/`.xyz` cells and partial/shared site
+ * occupancies. */
 int fdes_read_qsc(const char* file, fdes_params* p, fdes_atoms* atoms, int flags);
 /* Non-zero when libhdf5 (>= 1.10) could be loaded at run time (FDES_HDF5_LIB overrides the search). */
 int fdes_emd_available(void);

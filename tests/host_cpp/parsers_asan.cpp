@@ -202,7 +202,36 @@ int main(int argc, char** argv)
                 spit(T + "/SrTiO3.cfg", cfg);
             }
         }
-        std::printf("fuzz: 400 .cnf, 200 .qsc, 50 .cfg mutants parsed or refused\n");
+        // the same cell as .cssr and .dat (qsc.cpp read_cssr_* / read_dat_*): whole, cut short, mutated
+        const std::string cssr = " 3.905 3.905 3.905\n 90 90 90 SPGR = 1 P 1 OPT = 1\n 5 0\n SrTiO3\n"
+                                 "   1 Sr  0.0 0.0 0.0  0 0 0 0 0 0 0 0  0.6214\n   2 Ti1 0.5 0.5 0.5  0 0 0 0 0 0 0 0  0.4390\n"
+                                 "   3 O1  0.0 0.5 0.5  0 0 0 0 0 0 0 0  0.7323\n   4 O2  0.5 0.0 0.5  0 0 0 0 0 0 0 0  0.7323\n"
+                                 "   5 O3  0.5 0.5 0.0  0 0 0 0 0 0 0 0  0.7323\n";
+        const std::string dat = "Number of atoms = 5\na = 3.905\nb = 3.905\nc = 3.905\nalpha = 90\nbeta = 90\ngamma = 90\n"
+                                "Sr 0.0 0.0 0.0\nTi 0.5 0.5 0.5\n\nO  0.0 0.5 0.5\nO  0.5 0.0 0.5\nO  0.5 0.5 0.0\n";
+        const std::string base = "mode: TEM\nNCELLX: 2\nNCELLY: 2\nNCELLZ: 2\nslices: 4\nnx: 32\nv0: 80\nCs: 1.2\nalpha: 0.5\n";
+        spit(T + "/c.qsc", base + "filename: cell.cssr\n");
+        spit(T + "/d.qsc", base + "filename: cell.dat\n");
+        spit(T + "/cell.cssr", cssr);
+        spit(T + "/cell.dat", dat);
+        int nc = 0, nd = 0;
+        EXPECT(read_with(fdes_read_qsc, T + "/c.qsc", 0, &nc) == FDES_OK && nc == 40);
+        EXPECT(read_with(fdes_read_qsc, T + "/d.qsc", 0, &nd) == FDES_OK && nd == 40);
+        for (size_t cut : {(size_t)0, (size_t)5, (size_t)25, cssr.size() / 2, cssr.size() - 8}) {
+            spit(T + "/cell.cssr", cssr.substr(0, cut));
+            EXPECT(read_with(fdes_read_qsc, T + "/c.qsc", 0) != FDES_OK);
+        }
+        for (size_t cut : {(size_t)0, (size_t)12, dat.size() / 2, dat.size() - 20}) {
+            spit(T + "/cell.dat", dat.substr(0, cut));
+            EXPECT(read_with(fdes_read_qsc, T + "/d.qsc", 0) != FDES_OK);
+        }
+        for (int m = 0; m < 50; m++) {
+            spit(T + "/cell.cssr", mutate(cssr));
+            (void)read_with(fdes_read_qsc, T + "/c.qsc", 0);
+            spit(T + "/cell.dat", mutate(dat));
+            (void)read_with(fdes_read_qsc, T + "/d.qsc", 0);
+        }
+        std::printf("fuzz: 400 .cnf, 200 .qsc, 50 .cfg, 50 .cssr, 50 .dat mutants parsed or refused\n");
     }
     // ---- atoms from a flat array (the legacy export's path)
     {

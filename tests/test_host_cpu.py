@@ -443,12 +443,97 @@ def test_read_qsc_slices_from_thickness_and_celldiv(tmp_path):
 
 @pytest.mark.parametrize("kw, code", [
     (dict(mode="CBED"), -5), (dict(extra="tds: yes"), -5), (dict(extra="Cube: 10 10 10"), -5),
-    (dict(cfg="missing.cfg"), -2), (dict(cfg="cell.cssr"), -5)])
+    (dict(cfg="missing.cfg"), -2), (dict(cfg="missing.cssr"), -2), (dict(cfg="cell.pdb"), -5), (dict(cfg="cell.xyz"), -5)])
 def test_read_qsc_rejects_what_it_does_not_carry_over(tmp_path, kw, code):
     p = _write_qsc(tmp_path, **kw)
     with pytest.raises(fdes_amd.FdesError) as e:
         fdes_amd.read_qsc(p)
     assert e.value.code == code
+
+
+_SRTIO3_CSSR = """ 3.905 3.905 3.905
+ {angles} SPGR = {spgr} P 1 OPT = 1
+ 5 0
+ SrTiO3 written as a CSSR cell
+   1 Sr  0.0 0.0 0.0  0 0 0 0 0 0 0 0  0.6214
+   2 Ti1 0.5 0.5 0.5  0 0 0 0 0 0 0 0  0.4390
+   3 O1  0.0 0.5 0.5  0 0 0 0 0 0 0 0  0.7323
+   4 O2  0.5 0.0 0.5  0 0 0 0 0 0 0 0  0.7323
+   5 O3  0.5 0.5 0.0  0 0 0 0 0 0 0 0  0.7323
+"""
+_SRTIO3_DAT = """Number of atoms = 5
+a = 3.905
+b = 3.905
+c = 3.905
+alpha = 90
+beta = 90
+gamma = 90
+Sr 0.0 0.0 0.0
+Ti 0.5 0.5 0.5
+a comment line that names no element is skipped
+O  0.0 0.5 0.5
+O  0.5 0.0 0.5
+O  0.5 0.5 0.0
+"""
+
+
+def test_read_qsc_cssr_and_dat_cells(tmp_path):
+    """The vendored readUnitCell's other two formats (fileio_fftw3.cpp:666-713, 785-815, 825-895, 998-1052): the same
+    SrTiO3 cell as .cssr and as .dat gives the .cfg super cell, with the lattice parameters rounded to float as there
+    (MULS::ax is a float), the CSSR's last column as the Debye-Waller factor and the .dat rule 0.45*28/(2 Z)."""
+    f32 = np.float32
+    (tmp_path / "SrTiO3.cssr").write_text(_SRTIO3_CSSR.format(angles="90 90 90", spgr=1))
+    (tmp_path / "SrTiO3.dat").write_text(_SRTIO3_DAT)
+    Z0, xyz0, dwf0 = _srtio3_supercell(2, 3, 2, a=float(f32(3.905)))
+    p = _write_qsc(tmp_path, cfg="SrTiO3.cssr", extra="slices: 4")
+    hp, at = fdes_amd.read_qsc(p)
+    assert hp.c.material == b"SrTiO3" and hp.c.sample_name == b"SrTiO3_CELL_02_03_02"
+    assert np.array_equal(at.Z, Z0) and np.array_equal(at.xyz, xyz0) and np.array_equal(at.dwf, dwf0)
+    assert np.all(at.occ == 1)
+    # without an extension the .cssr is preferred over the .cfg (rwQsc.cu:181-210)
+    hp_b, at_b = fdes_amd.read_qsc(_write_qsc(tmp_path, cfg="SrTiO3", extra="slices: 4"))
+    assert np.array_equal(at_b.xyz, xyz0) and hp_b.c.d1 == hp.c.d1
+    _, at_cfg = fdes_amd.read_qsc(_write_qsc(tmp_path, cfg="SrTiO3.cfg", extra="slices: 4"))
+    assert np.allclose(at_cfg.xyz, xyz0, rtol=0, atol=1e-16)
+    hp_d, at_d = fdes_amd.read_qsc(_write_qsc(tmp_path, cfg="SrTiO3.dat", extra="slices: 4"))
+    assert np.array_equal(at_d.Z, Z0) and np.array_equal(at_d.xyz, xyz0) and hp_d.c.material == b"SrTiO3"
+    dw = f32(0.45 * 28.0 / (2.0 * Z0.astype(np.float64)))
+    assert np.array_equal(at_d.dwf, (dw.astype(np.float64) * 1e-20).astype(f32))
+
+
+def test_read_qsc_cssr_oblique_cell_and_refusals(tmp_path):
+    # gamma = 120: makeCellVectMuls (matrixlib.cpp:722-747) sets b = by*(cos g, cos g, 0) - kept as it is there
+    (tmp_path / "SrTiO3.cssr").write_text(_SRTIO3_CSSR.format(angles="90 90 120", spgr=1))
+    p = _write_qsc(tmp_path, cfg="SrTiO3.cssr", ncz="1", extra="slices: 2")
+    hp, at = fdes_amd.read_qsc(p)
+    a = float(np.float32(3.905))
+    d = 1.7453292519943e-2
+    cg = np.cos(120 * d)
+    Mm = np.array([[a, 0, 0], [a * cg, a * cg, 0], [a * np.cos(90 * d), a * (np.cos(90 * d) - np.cos(90 * d) * cg) / np.sin(120 * d),
+                                                     a * np.sqrt(1 - 2 * np.cos(90 * d) ** 2 + 2 * np.cos(90 * d) ** 2 * cg) / np.sin(120 * d)]])
+    corners = np.array([[i, j, k] for i in (0, 2) for j in (0, 3) for k in (0, 1)], float) @ Mm
+    ext = corners.max(0) - corners.min(0)
+    assert abs(hp.c.d1 * hp.c.n1 - ext[0] * 1e-10) < 1e-16 and abs(hp.c.d3 * hp.c.m3 - ext[2] * 1e-10) < 1e-16
+    cell = [(0, 0, 0), (.5, .5, .5), (0, .5, .5), (.5, 0, .5), (.5, .5, 0)]
+    cell.sort(key=lambda t: (t[2], t[1], t[0]))
+    want = np.array([(np.array(cell[i]) + (icx, icy, 0)) @ Mm - corners.min(0)
+                     for icx in range(2) for icy in range(3) for i in range(5)]) * 1e-10
+    want = want.reshape(2, 3, 5, 3).reshape(-1, 3)
+    lo = np.minimum(want.min(0), 1.0)
+    hi = np.maximum(want.max(0), 0.0)
+    assert at.n == 30 and np.allclose(at.xyz, want - (hi - lo) / 2, rtol=0, atol=2e-16)
+    for text, code in ((_SRTIO3_CSSR.format(angles="90 90 90", spgr=2), -5),
+                       (_SRTIO3_CSSR.format(angles="90 90 90", spgr=1).replace("SPGR =", "SPGR:"), -1),
+                       (_SRTIO3_CSSR.format(angles="90 90 90", spgr=1).replace("  0 0 0 0 0 0 0 0  0.6214", ""), -1),
+                       (_SRTIO3_CSSR.format(angles="90 90 90", spgr=1).replace(" 5 0\n", " 6 0\n"), -1)):
+        (tmp_path / "SrTiO3.cssr").write_text(text)
+        with pytest.raises(fdes_amd.FdesError) as e:
+            fdes_amd.read_qsc(p)
+        assert e.value.code == code
+    (tmp_path / "SrTiO3.dat").write_text(_SRTIO3_DAT.replace("Number of atoms = 5", "Number of atoms = 6"))
+    with pytest.raises(fdes_amd.FdesError) as e:
+        fdes_amd.read_qsc(_write_qsc(tmp_path, cfg="SrTiO3.dat", extra="slices: 4"))
+    assert e.value.code == -1
 
 
 def test_read_qsc_needs_the_keys_the_reference_exits_on(tmp_path):
