@@ -176,6 +176,7 @@ PROTOTYPES = [
     ("fdes_plan_fft_backend", C.c_int, [_vp]),
     ("fdes_grid_backend", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("fdes_plan_lanes", C.c_int, [_vp]),
+    ("fdes_plan_gang", C.c_int, [_vp]),
     ("fdes_plan_num_slices", C.c_int, [_vp]),
     ("fdes_plan_slices_done", C.c_int64, [_vp]),
     ("fdes_plan_empty_queries", C.c_int64, [_vp]),

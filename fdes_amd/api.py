@@ -302,6 +302,9 @@ class Plan:
     def lanes(self):
         return int(self.lib.fdes_plan_lanes(self.h))
 
+    def gang(self):
+        return int(self.lib.fdes_plan_gang(self.h))
+
     def slices_done(self):
         return int(self.lib.fdes_plan_slices_done(self.h))
 

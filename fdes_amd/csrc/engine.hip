@@ -54,6 +54,8 @@ struct fdes_ctx {
                           // wave's passes (P5, P6): concurrency inside ONE configuration; -1 auto, 0 off, 1 on (issued
                           // directly, never captured into a graph)
     int batch = -1;       // slice pairs per launch of the potential chain of a one-lane plan: -1 auto (by grid size), 0 / 1 off, 2 ... 8
+    int gang = -1;        // configurations of one measurement whose slice loops run in lockstep on one lane, every pass ONE launch
+                          // (grid z = configuration): -1 auto (by grid size), 0 / 1 off, 2 ... 16
     int stagger = 0;      // one-wave-per-row passes: start delay between the waves of a CU, in units of 64 cycles (0: none)
     int walk = 1;         // every pass is launched in this many parts (2: a part takes half of the workgroup slots, two lanes' passes share every CU)
     int pitch_pad = -1;   // elements added to every row of the fused loop's grids; -1 auto: 32 for 2048-point rows, 64 from 4096 on
@@ -75,7 +77,7 @@ struct fdes_ctx {
     int64_t progress_done = 0;
 };
 
-struct EvPair { hipEvent_t a, b; int slices; };
+struct EvPair { hipEvent_t a, b; int slices; int configs = 1; };
 
 struct fdes_plan {
     fdes_ctx* ctx = nullptr;
@@ -161,6 +163,18 @@ struct fdes_plan {
     int nb = 1;
     float2 *bA = nullptr, *bB = nullptr, *bCC = nullptr, *bE[2] = {nullptr, nullptr};
     hipEvent_t evReady[2] = {nullptr, nullptr}, evDone[2] = {nullptr, nullptr};
+    // gang of configurations: run_config only queues; `gang` queued configurations of one measurement are
+    // then issued together - atoms and incoming wave per member, ONE slice loop whose passes carry the members as grid z.
+    // The buffers the passes touch hold `gang` members back to back (member 0 = the plan's own pointers).
+    int gang = 1;                         // members (1: off)
+    int gn = 1;                           // members of the gang being issued (pass launches: nbatch)
+    struct GangCfg { int k, j; float w; };
+    std::vector<GangCfg> gq;              // queued configurations (all of one measurement k)
+    std::vector<AtomBins> gbins;          // member views of the binning buffers
+    std::vector<std::vector<int>> gseg;   // members' (slice, species) segment tables (skip_empty)
+    float* gxyzFP = nullptr;              // [gang][3 nAt] jittered coordinates (member 0 = xyzFP_d)
+    std::vector<void*> gang_owned;        // per-member binning arrays of members >= 1
+    size_t recs_stride = 0, rowstart_stride = 0;
     float2* peer_stage = nullptr;   // landing buffer for another GPU's partial sum (fdes_plan_accumulate_from)
     bool peer_host_only = false;    // the peer copy was refused once: partial sums are staged through host memory (option "peer_copy" 0 forces it)
     std::vector<float2> peer_host;
@@ -169,6 +183,7 @@ struct fdes_plan {
     std::vector<EvPair> evs;
     size_t ev_used = 0;
     size_t ev_done = 0; // events of one stream complete in order: evs[i].b has been seen complete for i < ev_done
+    int64_t cfg_done = 0; // configurations behind those events (a gang's pair of events stands for all its members)
     int64_t slices_done = 0;
 };
 
@@ -391,6 +406,14 @@ PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->
 // stream of the potential / transmission passes
 hipStream_t vstream(fdes_plan* pl) { return (pl->split && !pl->tap_mode) ? pl->vs : pl->ctx->stream; }
 
+// gang (fdes_plan::gn members in one launch, grid z = member): element strides of the operands between members
+void gang_strides(const fdes_plan* pl, PassArgs& a, size_t in0, size_t out, size_t out2 = 0, size_t in1 = 0)
+{
+    if (pl->gn <= 1) return;
+    a.nbatch = pl->gn;
+    a.bstride_in0 = in0; a.bstride_out = out; a.bstride_out2 = out2; a.bstride_in1 = in1;
+}
+
 // Potential of the slice PAIR (s0, s0 + 1), s0 even: W = V_s0 + i V_(s0+1) (the deposits are real and the filter
 // G is real and even, so one complex transform carries two slices).  P1' builds the x-spectra of the deposit rows
 // straight from the sorted atom records (no deposit grid), P2 applies the filter in (kx, ky) and sums the species.
@@ -405,10 +428,16 @@ int fused_potential_pair(fdes_plan* pl, int s0)
         a.recs = pl->bins.recs_sorted; a.rowstart = pl->bins.rowstart;
         a.q0 = s0 * pl->nZ;
         a.q1 = (s0 + 1 < pl->p.m3) ? (s0 + 1) * pl->nZ : -1;
+        gang_strides(pl, a, 0, pl->gsz * (size_t)pl->nZ);
+        if (pl->gn > 1) { // every member deposits the same slice pair from its own records
+            a.bstride_recs = pl->recs_stride; a.bstride_rowstart = pl->rowstart_stride;
+            for (int g = 0; g < pl->gn; g++) { a.zq0[g] = a.q0; a.zq1[g] = a.q1; }
+        }
         HIPCHK(c, lds_pass(m1, XF_FWD, MID_ATOMS, XF_NONE, true, a, vstream(pl)));
     }
     PassArgs b = pass_y(pl);
     b.in0 = pl->A; b.gtab = pl->GT; b.out = pl->B; b.nspecies = pl->nZ; b.species_stride = pl->gsz;
+    gang_strides(pl, b, pl->gsz * (size_t)pl->nZ, pl->gsz);
     HIPCHK(c, lds_pass(m2, XF_FWD, pl->nZ == 1 ? MID_GTAB : MID_GTABN, XF_INV, true, b, vstream(pl)));
     return FDES_OK;
 }
@@ -463,6 +492,7 @@ int fused_empty_run(fdes_plan* pl, int s, int nslices, int* consumed)
     // (an incoming wave that is not band-limited in kx needs no special case here: the dead kx rows this copy drops are
     // zeroed by the masked propagator whatever they held)
     a5.band = band; a5.skip_dead_loads = bs; a5.skip_dead_stores = bs;
+    gang_strides(pl, a5, pl->gsz, pl->gsz);
     HIPCHK(c, lds_pass(m1, XF_NONE, MID_SCALE, XF_NONE, true, a5, c->stream));
     int run = 1;
     while (s + run < nslices && empty(s + run)) run++;
@@ -471,8 +501,9 @@ int fused_empty_run(fdes_plan* pl, int s, int nslices, int* consumed)
     PassArgs a6 = pass_y(pl);
     a6.in0 = pl->F; a6.prow = ptab; a6.pcol = ptab + m1; a6.mindim = md; a6.out = pl->PSIH;
     a6.band = band; a6.live_rows_only = bs;
+    gang_strides(pl, a6, pl->gsz, pl->gsz);
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
-    pl->slices_skipped += run;
+    pl->slices_skipped += (int64_t)run * pl->gn;
     *consumed = run;
     return FDES_OK;
 }
@@ -492,6 +523,7 @@ int fused_wave_step(fdes_plan* pl, int s, const float2* E, int ei)
     // configuration sees the incoming wave, which the reference multiplies by t in full (src/multisliceSimulation.cu:546)
     // and which is not band-limited in kx when a tilted CBED probe leaves the band (:583-590) - then all of it is read.
     a5.band = band; a5.skip_dead_loads = bs ? ((s == 0 && !pl->wave_bl) ? 1 : 3) : 0; a5.skip_dead_stores = bs;
+    gang_strides(pl, a5, pl->gsz, pl->gsz, 0, pl->gsz);
     // roofline probe: P5 is the longest kernel of the loop; every probe_stride-th launch is bracketed by events
     const int pstride = owner_ctx(pl)->probe_stride;
     const bool probe = !pl->capturing && pstride > 0 && (pl->fft_calls++ % (uint64_t)pstride) == 0;
@@ -515,6 +547,7 @@ int fused_wave_step(fdes_plan* pl, int s, const float2* E, int ei)
     PassArgs a6 = pass_y(pl);
     a6.in0 = pl->F; a6.prow = pl->PT; a6.pcol = pl->PT + m1; a6.mindim = md; a6.out = pl->PSIH;
     a6.band = band; a6.live_rows_only = bs;
+    gang_strides(pl, a6, pl->gsz, pl->gsz);
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
     return FDES_OK;
 }
@@ -540,6 +573,7 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
         PassArgs a3 = pass_x(pl);
         a3.in0 = pl->B; a3.out = pl->C; a3.out2 = pl->C2; a3.scale = pl->p.imPot;
         a3.band = band; a3.skip_dead_stores = bs;
+        gang_strides(pl, a3, pl->gsz, pl->gsz, pl->gsz);
         HIPCHK(c, lds_pass(m1, XF_INV, MID_EXPIV_PAIR, XF_FWD, true, a3, vstream(pl)));
     }
     const bool split = pl->split && !pl->tap_mode;
@@ -547,6 +581,7 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
     PassArgs a4 = pass_y(pl);
     a4.in0 = (s & 1) ? pl->C2 : pl->C; a4.out = pl->Eb[ei]; a4.scale = 1.f / ((float)pl->m12); a4.mindim = md;
     a4.band = band; a4.live_rows_only = bs;
+    gang_strides(pl, a4, pl->gsz, pl->gsz);
     if (split && pl->p5_seen[ei]) HIPCHK(c, hipStreamWaitEvent(pl->vs, pl->evP5[ei], 0)); // the wave chain has consumed this buffer
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, vstream(pl)));
     if (split) {
@@ -662,6 +697,7 @@ int fused_enter(fdes_plan* pl)
     PassArgs a = pass_x(pl);
     a.in0 = pl->PSI; a.out = pl->PSIH;
     a.pitch_in = 0; a.pitch_out = pl->pitchN; // dense real-space wave -> padded mixed representation, natural store
+    gang_strides(pl, a, pl->m12, pl->gsz);
     HIPCHK(pl->ctx, lds_pass(pl->p.m1, XF_FWD, MID_NONE, XF_NONE, false, a, pl->ctx->stream));
     return FDES_OK;
 }
@@ -676,6 +712,7 @@ int fused_leave(fdes_plan* pl, bool propagated)
     }
     a.pitch_out = 0; // dense
     a.scale = 1.f / (float)pl->p.m1; // PSIH = FFT_x(psi), unnormalised transforms (m1 is a power of two: exact)
+    gang_strides(pl, a, pl->gsz, pl->m12);
     HIPCHK(pl->ctx, lds_pass(pl->p.m1, XF_INV, MID_SCALE, XF_NONE, false, a, pl->ctx->stream));
     return FDES_OK;
 }
@@ -743,6 +780,7 @@ int slice_loop(fdes_plan* pl, int nslices)
     pattern.push_back((uint8_t)(oc->stagger >> 8));
     pattern.push_back((uint8_t)(pl->split ? 1 : 0));
     pattern.push_back((uint8_t)(pl->wave_bl ? 1 : 0));
+    pattern.push_back((uint8_t)pl->gn);
     pattern.push_back(pl->seg_h.empty() ? 0 : 1);
     if (!pl->seg_h.empty())
         for (int q = 0; q < pl->p.m3; q++) pattern.push_back(pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ] ? 2 : 3);
@@ -817,12 +855,85 @@ int exit_wave_post(fdes_plan* pl, int k, float weight)
     return FDES_OK;
 }
 
+// The queued configurations of this plan (all of measurement k) as ONE gang: the incoming wave once (it depends on k
+// only) and copied to the members, atoms / records per member, one slice loop with the members as grid z, the detector
+// chain per member.  A slice counts as empty (skip_empty) only when it is empty in every member: the others run the
+// full sequence on it, which is always correct (t = band-limited 1).
+int gang_flush(fdes_plan* pl)
+{
+    const int n = (int)pl->gq.size();
+    if (n == 0) return FDES_OK;
+    fdes_ctx* c = pl->ctx;
+    const int k = pl->gq[0].k;
+    RC(incoming_wave(pl, k));
+    for (int g = 1; g < n; g++)
+        HIPCHK(c, hipMemcpyAsync(pl->PSI + (size_t)g * pl->m12, pl->PSI, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
+    float* const xyz0 = pl->xyzFP_d;
+    const AtomBins bins0 = pl->bins;
+    bool have_all = true;
+    for (int g = 0; g < n; g++) {
+        pl->xyzFP_d = pl->gxyzFP + (size_t)g * 3 * (size_t)pl->nAt;
+        pl->bins = pl->gbins[(size_t)g];
+        const int rc = config_atoms(pl, k, pl->gq[(size_t)g].j);
+        pl->xyzFP_d = xyz0;
+        pl->bins = bins0;
+        RC(rc);
+        pl->gseg[(size_t)g] = pl->seg_h;
+        have_all = have_all && !pl->seg_h.empty();
+    }
+    // empty in every member <=> the SUM of the members' (monotone) segment tables does not move
+    if (have_all) {
+        pl->seg_h.assign(pl->gseg[0].size(), 0);
+        for (int g = 0; g < n; g++)
+            for (size_t i = 0; i < pl->seg_h.size(); i++) pl->seg_h[i] += pl->gseg[(size_t)g][i];
+    } else {
+        pl->seg_h.clear();
+    }
+    if (pl->ev_used == pl->evs.size()) {
+        EvPair e{};
+        HIPCHK(c, hipEventCreate(&e.a));
+        HIPCHK(c, hipEventCreate(&e.b));
+        pl->evs.push_back(e);
+    }
+    EvPair& ev = pl->evs[pl->ev_used++];
+    ev.slices = pl->p.m3 * n;
+    ev.configs = n;
+    HIPCHK(c, hipEventRecord(ev.a, c->stream));
+    pl->gn = n;
+    const int rcl = slice_loop(pl, pl->p.m3);
+    pl->gn = 1;
+    RC(rcl);
+    HIPCHK(c, hipEventRecord(ev.b, c->stream));
+    pl->slices_done += (int64_t)pl->p.m3 * n;
+    float2* const psi0 = pl->PSI;
+    int rce = FDES_OK;
+    for (int g = 0; g < n && rce == FDES_OK; g++) {
+        pl->PSI = psi0 + (size_t)g * pl->m12;
+        rce = exit_wave_post(pl, k, pl->gq[(size_t)g].w);
+    }
+    pl->PSI = psi0;
+    pl->gq.clear();
+    return rce;
+}
+
+// everything queued on this plan and its lanes is issued (before anything reads or resets the sums)
+int gang_flush_all(fdes_plan* pl)
+{
+    RC(gang_flush(pl));
+    for (fdes_plan* l : pl->lanes) {
+        const int rc = gang_flush(l);
+        if (rc != FDES_OK) { pl->ctx->err = "lane: " + l->ctx->err; return rc; }
+    }
+    return FDES_OK;
+}
+
 // Lane 0 takes over the partial sums of the other lanes: I += I_lane (and the exit-wave sum), ordered by
 // events in both directions (lane stream -> lane 0 before the read, lane 0 -> lane stream before the lane
 // reuses its accumulators).
 int fold_lanes(fdes_plan* pl)
 {
     fdes_ctx* c = pl->ctx;
+    RC(gang_flush_all(pl));
     if (!pl->lanes_dirty) return FDES_OK;
     for (size_t l = 0; l < pl->lanes.size(); l++) {
         fdes_plan* lp = pl->lanes[l];
@@ -847,9 +958,9 @@ int64_t configs_finished(fdes_plan* pl, hipEvent_t* oldest_pending)
 {
     int64_t n = 0;
     auto scan = [&](fdes_plan* q) {
-        while (q->ev_done < q->ev_used && hipEventQuery(q->evs[q->ev_done].b) == hipSuccess) q->ev_done++;
+        while (q->ev_done < q->ev_used && hipEventQuery(q->evs[q->ev_done].b) == hipSuccess) q->cfg_done += q->evs[q->ev_done++].configs;
         (void)hipGetLastError(); // hipErrorNotReady is not an error
-        n += (int64_t)q->ev_done;
+        n += q->cfg_done;
         if (oldest_pending && !*oldest_pending && q->ev_done < q->ev_used) *oldest_pending = q->evs[q->ev_done].b;
     };
     scan(pl);
@@ -879,12 +990,39 @@ void report_progress(fdes_plan* pl, int64_t issued, int64_t total_configs, bool 
 // Configurations a plan keeps in flight: lanes hide the gap between dependent kernels of one stream - three up to 1024^2,
 // where the kernels are no longer than that gap, two above - but never more than the job has configurations (n3 x
 // frozen-phonon configurations): a single image gets one lane, and its concurrency from the split slice loop instead.
+// (A fourth lane at 1024^2 is 43 k slice-propagations/s on C4 against 38 k with three - or 17 k: which of the two depends
+// on the hardware queues the runtime happens to hand out, i.e. on what the process created before; six / eight lanes
+// 25 k / 20 k; GPU_MAX_HW_QUEUES changes nothing.  tools/exp/c4_job.py, tools/exp/stream_overlap.hip.)
+// Members of a gang (configurations of ONE measurement in lockstep on a lane): only the fused loop on one stream takes
+// them, and never more than a measurement has configurations
+int plan_gang(const fdes_ctx* c, const fdes_plan* pl)
+{
+    const int count = pl->p.frPh > 0 ? pl->p.frPh : 1;
+    if (c->gang == 0 || c->gang == 1 || count < 2) return 1;
+    if (c->opt_fft == 1 || !Fft2D::lds_supported(pl->p.m1, pl->p.m2)) return 1;
+    if (c->split > 0 || c->batch > 1 || c->pass_threads == 65 || c->walk > 1) return 1;
+    // auto (tools/bench_c4.py, SrTiO3 tilt series with 16 configurations per tilt, slice-propagations/s without a gang on
+    // three lanes -> with it on two): 256^2 76 k -> 226 k with 8 members (4: 155 k, 16 on one lane: 191 k), 512^2 53 k -> 121 k
+    // with 8 (4: 97 k), 800^2 22 k -> 28 k with 4 (8: 27 k), 1024^2 38 k -> 45 k with 4 (2: 40 k, 8: 40 k); from 2048^2 on one
+    // configuration's rows fill the chip.  At least two gangs per measurement, so that two lanes have work.
+    int g = c->gang;
+    if (g < 0) {
+        const size_t m12 = (size_t)pl->p.m1 * (size_t)pl->p.m2;
+        g = m12 <= ((size_t)1 << 18) ? 8 : (m12 <= ((size_t)1 << 20) ? 4 : 1);
+        if (count >= 4 && g > count / 2) g = count / 2;
+    }
+    if (g > 16) g = 16;
+    return g < count ? g : count;
+}
+
 int plan_lanes(const fdes_ctx* c, const fdes_plan* pl)
 {
     if (c->is_lane_ctx) return 1;
-    if (c->lanes > 0) return c->lanes;
-    const long total = (long)pl->p.n3 * (long)(pl->p.frPh > 0 ? pl->p.frPh : 1);
-    const int by_size = (pl->fused && pl->m12 <= (size_t)1024 * 1024) ? 3 : 2;
+    const int g = plan_gang(c, pl);
+    long total = (long)pl->p.n3 * (long)(pl->p.frPh > 0 ? pl->p.frPh : 1);
+    if (g > 1) total = (long)pl->p.n3 * (((long)pl->p.frPh + g - 1) / g); // gangs in flight, not configurations
+    if (c->lanes > 0) return g > 1 ? (int)(total < c->lanes ? total : c->lanes) : c->lanes;
+    const int by_size = (pl->fused && pl->m12 <= (size_t)1024 * 1024 && g == 1) ? 3 : 2; // (gangs: two lanes measured equal to or better than three)
     return (int)(total < by_size ? total : by_size);
 }
 
@@ -999,6 +1137,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
     if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 64 && value != 65 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "split")) { if (value < -1 || value > 1) return FDES_EINVAL; c->split = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "gang")) { if (value < -1 || value > 16) return FDES_EINVAL; c->gang = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "batch")) { if (value < -1 || value > 8) return FDES_EINVAL; c->batch = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "stagger")) { if (value < 0 || value > 1024) return FDES_EINVAL; c->stagger = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "walk")) { if (value < 1 || value > 8) return FDES_EINVAL; c->walk = (int)value; return FDES_OK; }
@@ -1011,7 +1150,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "bench_pitch")) { if (value < 0 || value > 4096) return FDES_EINVAL; c->bench_pitch = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "skip_empty")) { c->skip_empty = value != 0; return FDES_OK; }
-    if (!std::strcmp(key, "lanes")) { if (value < 0 || value > 4) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "lanes")) { if (value < 0 || value > 8) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "deterministic")) { c->deterministic = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "peer_copy")) { c->peer_copy = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "probe_stride")) { c->probe_stride = (int)value; return FDES_OK; }
@@ -1036,6 +1175,8 @@ int fdes_plan_destroy(fdes_plan* pl)
                     pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A == pl->C ? nullptr : pl->A, pl->C, pl->C2, pl->E, pl->PSIH,
                     pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT, pl->peer_stage}; // F aliases C
     for (void* q : ptrs) if (q) (void)hipFree(q);
+    for (void* q : pl->gang_owned) if (q) (void)hipFree(q);
+    pl->gang_owned = {}; pl->gbins = {}; pl->gseg = {}; pl->gq = {};
     for (auto& g : pl->graphs) { (void)hipGraphExecDestroy(g.exec); for (auto& e : g.pow) (void)hipFree(e.second); }
     for (auto& e : pl->pow_tabs) if (e.tab) (void)hipFree(e.tab);
     for (auto& e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1100,7 +1241,10 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLCHK(dmalloc(c, &pl->xyz0_d, n3f));
     PLCHK(dmalloc(c, &pl->xyzTO_d, n3f));
     PLCHK(dmalloc(c, &pl->xyzK_d, n3f));
-    PLCHK(dmalloc(c, &pl->xyzFP_d, n3f));
+    pl->gang = plan_gang(c, pl);
+    const size_t G = (size_t)pl->gang;
+    PLCHK(dmalloc(c, &pl->xyzFP_d, n3f * G));
+    pl->gxyzFP = pl->xyzFP_d;
     PLCHK(dmalloc(c, &pl->dwf_d, (size_t)nAt));
     PLCHK(dmalloc(c, &pl->occ_d, (size_t)nAt));
     if (nAt > 0) {
@@ -1120,10 +1264,26 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLCHK(dmalloc(c, &pl->bins.order, (size_t)nAt));
     PLCHK(dmalloc(c, &pl->bins.seg, (size_t)pl->bins_cap_keys + 2));
     PLCHK(dmalloc(c, &pl->bins.recs, (size_t)nAt));
-    PLCHK(dmalloc(c, &pl->bins.recs_sorted, (size_t)nAt));
-    PLCHK(dmalloc(c, &pl->bins.rowstart, (size_t)m3max * pl->nZ * (size_t)(pl->p.m2 + 1))); // first sorted position of every (slice, species, row)
+    pl->recs_stride = (size_t)(nAt > 0 ? nAt : 1);
+    pl->rowstart_stride = (size_t)m3max * pl->nZ * (size_t)(pl->p.m2 + 1);
+    PLCHK(dmalloc(c, &pl->bins.recs_sorted, pl->recs_stride * G)); // (gang: the members' sorted records and row tables back to back)
+    PLCHK(dmalloc(c, &pl->bins.rowstart, pl->rowstart_stride * G)); // first sorted position of every (slice, species, row)
     pl->bins.tmp_bytes = geom_sort_temp_bytes(nAt);
     PLHIP(hipMalloc(&pl->bins.tmp, pl->bins.tmp_bytes > 0 ? pl->bins.tmp_bytes : 16));
+    pl->gbins.assign(G, pl->bins);
+    pl->gseg.assign(G, {});
+    for (size_t g = 1; g < G; g++) { // members >= 1: own key / order / segment arrays, shared sort scratch (one stream)
+        AtomBins& b = pl->gbins[g];
+        b.recs_sorted = pl->bins.recs_sorted + g * pl->recs_stride;
+        b.rowstart = pl->bins.rowstart + g * pl->rowstart_stride;
+        b.keys = b.keys_sorted = b.vals = b.order = nullptr; b.seg = nullptr; b.recs = nullptr;
+        PLCHK(dmalloc(c, &b.keys, (size_t)nAt)); pl->gang_owned.push_back(b.keys);
+        PLCHK(dmalloc(c, &b.keys_sorted, (size_t)nAt)); pl->gang_owned.push_back(b.keys_sorted);
+        PLCHK(dmalloc(c, &b.vals, (size_t)nAt)); pl->gang_owned.push_back(b.vals);
+        PLCHK(dmalloc(c, &b.order, (size_t)nAt)); pl->gang_owned.push_back(b.order);
+        PLCHK(dmalloc(c, &b.seg, (size_t)pl->bins_cap_keys + 2)); pl->gang_owned.push_back(b.seg);
+        PLCHK(dmalloc(c, &b.recs, (size_t)nAt)); pl->gang_owned.push_back(b.recs);
+    }
     {   // enough blocks for an average segment, capped; the kernel strides over the rest
         long avg = (long)nAt / (pl->p.m3 > 0 ? pl->p.m3 : 1) + 1;
         long b = (avg * 4 + 255) / 256;
@@ -1132,7 +1292,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLCHK(dmalloc(c, &pl->D, pl->m12));
     PLCHK(dmalloc(c, &pl->VH, pl->m12));
     PLCHK(dmalloc(c, &pl->T, pl->m12));
-    PLCHK(dmalloc(c, &pl->PSI, pl->m12));
+    PLCHK(dmalloc(c, &pl->PSI, pl->m12 * G));
     PLCHK(dmalloc(c, &pl->P, pl->m12));
     PLCHK(dmalloc(c, &pl->I, pl->m12));
     PLCHK(dmalloc(c, &pl->EW, pl->m12));
@@ -1213,15 +1373,16 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
                 if (c->batch > 1) nb = c->batch;
                 else if (c->batch < 0) nb = pl->m12 <= ((size_t)1 << 18) ? 8 : (pl->m12 <= ((size_t)1 << 20) ? 4 : 1); // measured (tools/bench_single.py): 512^2 8 > 4 > 2; 1024^2 4 >= 2, 8 lower
             }
+            if (pl->gang > 1) { nb = 1; pl->split = false; } // a gang fills the launches with configurations instead
             pl->nb = nb;
             if (nb > 1) pl->split = true;
         }
-        PLCHK(dmalloc(c, &pl->C, pl->gsz));
+        PLCHK(dmalloc(c, &pl->C, pl->gsz * G));
         if (pl->split) PLCHK(dmalloc(c, &pl->F, pl->gsz)); else pl->F = pl->C;
         if (pl->nZ == 1) pl->A = pl->C;
-        else PLCHK(dmalloc(c, &pl->A, pl->gsz * (size_t)pl->nZ));
-        PLCHK(dmalloc(c, &pl->C2, pl->gsz)); // x-spectrum of the transmission function of the pair's second slice
-        PLCHK(dmalloc(c, &pl->E, pl->gsz));
+        else PLCHK(dmalloc(c, &pl->A, pl->gsz * (size_t)pl->nZ * G));
+        PLCHK(dmalloc(c, &pl->C2, pl->gsz * G)); // x-spectrum of the transmission function of the pair's second slice
+        PLCHK(dmalloc(c, &pl->E, pl->gsz * G));
         pl->Eb[0] = pl->Eb[1] = pl->E;
         if (pl->split) {
             PLCHK(dmalloc(c, &pl->Eb[1], pl->gsz));
@@ -1248,14 +1409,14 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
                 PLHIP(hipEventCreateWithFlags(&pl->evDone[q], hipEventDisableTiming));
             }
         }
-        PLCHK(dmalloc(c, &pl->PSIH, pl->gsz));
+        PLCHK(dmalloc(c, &pl->PSIH, pl->gsz * G));
         if (c->share_PT) { pl->PT = c->share_PT; pl->GT = c->share_GT; pl->tables_shared = true; }
         else {
             PLCHK(dmalloc(c, &pl->PT, (size_t)pl->p.m1 + (size_t)pl->p.m2));
             PLCHK(dmalloc(c, &pl->GT, pl->gsz * (size_t)pl->nZ));
         }
         // dead (band-limited) rows / columns of these grids are never written again: they must read as zero
-        for (float2* q : {pl->C, pl->C2, pl->E, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->gsz, c->stream));
+        for (float2* q : {pl->C, pl->C2, pl->E, pl->PSIH}) PLHIP(hipMemsetAsync(q, 0, sizeof(float2) * pl->gsz * G, c->stream));
         if (!pl->tables_shared) {
             PLHIP(k_build_propagator_1d(pl->PT, pl->PT + pl->p.m1, pl->kp, 1, c->stream));
             PLHIP(hipMemsetAsync(pl->GT, 0, sizeof(float) * pl->gsz * (size_t)pl->nZ, c->stream));
@@ -1275,10 +1436,12 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     if (nlanes > 1 && !c->is_lane_ctx) {
         for (int l = 1; l < nlanes; l++) {
             fdes_ctx* lc = nullptr;
-            PLCHK(create_ctx(&lc, c->device, nlanes >= 3 ? (l <= 2 ? l : 0) : 0));
+            int prio = nlanes >= 3 ? l % 3 : 0;
+            if (const char* e = std::getenv("FDES_EXP_LANE_PRIO")) { if ((int)std::strlen(e) > l && e[l] >= '0' && e[l] <= '2') prio = e[l] - '0'; } // experiment: priority class per lane, e.g. "0120"
+            PLCHK(create_ctx(&lc, c->device, prio));
             lc->is_lane_ctx = true;
             // frozen here: fft, lanes, pass_threads (they shape the lane plan); the others are read through owner_ctx()
-            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad; lc->split = pl->split ? 1 : 0; lc->batch = c->batch > 1 ? c->batch : 0;
+            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad; lc->split = pl->split ? 1 : 0; lc->batch = c->batch > 1 ? c->batch : 0; lc->gang = pl->gang; lc->walk = c->walk;
             lc->share_PT = pl->PT; lc->share_GT = pl->GT; // read-only tables of the parent plan (built and synchronised above)
             pl->lane_ctx.push_back(lc);
             fdes_plan* lp = nullptr;
@@ -1304,6 +1467,7 @@ int fdes_plan_begin_measurement(fdes_plan* pl, int k)
     if (!live_plan(pl) || k < 0 || k >= pl->p.n3) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
+    if (!pl->is_lane) { RC(gang_flush_all(pl)); pl->rr = 0; }
     HIPCHK(c, k_fill(pl->I, pl->m12, 0.f, 0.f, c->stream));
     if (pl->want_ew) HIPCHK(c, k_fill(pl->EW, pl->m12, 0.f, 0.f, c->stream));
     for (fdes_plan* l : pl->lanes) { l->want_ew = pl->want_ew; RC(fdes_plan_begin_measurement(l, k)); }
@@ -1318,13 +1482,19 @@ int fdes_plan_run_config(fdes_plan* pl, int k, int j, float weight)
     if (!pl->lanes.empty()) {
         unsigned nl = (unsigned)(pl->lanes.size() + 1);
         if (c->lanes_active > 0 && (unsigned)c->lanes_active < nl) nl = (unsigned)c->lanes_active;
-        const unsigned lane = pl->rr++ % nl;
+        // round robin; with gangs a lane is dealt configurations until its gang is full
+        const unsigned lane = (pl->gang > 1 ? pl->rr++ / (unsigned)pl->gang : pl->rr++) % nl;
         if (lane > 0) {
             pl->lanes_dirty = true;
             int rcl = fdes_plan_run_config(pl->lanes[lane - 1], k, j, weight);
             if (rcl != FDES_OK) c->err = "lane: " + pl->lanes[lane - 1]->ctx->err;
             return rcl;
         }
+    }
+    if (pl->gang > 1 && pl->fused && !pl->tap_mode && owner_ctx(pl)->probe_stride <= 0) {
+        if (!pl->gq.empty() && pl->gq[0].k != k) RC(gang_flush(pl));
+        pl->gq.push_back({k, j, weight});
+        return (int)pl->gq.size() >= pl->gang ? gang_flush(pl) : FDES_OK;
     }
     RC(incoming_wave(pl, k));
     RC(config_atoms(pl, k, j));
@@ -1415,6 +1585,7 @@ int fdes_plan_sync(fdes_plan* pl)
 {
     if (!live_plan(pl)) return FDES_EINVAL;
     HIPCHK(pl->ctx, hipSetDevice(pl->ctx->device));
+    RC(gang_flush_all(pl));
     for (fdes_plan* l : pl->lanes) { if (l->vs) HIPCHK(pl->ctx, hipStreamSynchronize(l->vs)); HIPCHK(pl->ctx, hipStreamSynchronize(l->ctx->stream)); }
     if (pl->vs) HIPCHK(pl->ctx, hipStreamSynchronize(pl->vs));
     HIPCHK(pl->ctx, hipStreamSynchronize(pl->ctx->stream));
@@ -1438,6 +1609,7 @@ int fdes_grid_backend(int m1, int m2, int fft_option)
 }
 int fdes_plan_fft_backend(const fdes_plan* pl) { return live_plan(pl) ? pl->fft->backend : FDES_EINVAL; }
 int fdes_plan_lanes(const fdes_plan* pl) { return live_plan(pl) ? (int)pl->lanes.size() + 1 : FDES_EINVAL; }
+int fdes_plan_gang(const fdes_plan* pl) { return live_plan(pl) ? pl->gang : FDES_EINVAL; }
 int fdes_plan_num_slices(const fdes_plan* pl) { return live_plan(pl) ? pl->p.m3 : FDES_EINVAL; }
 int64_t fdes_plan_empty_queries(const fdes_plan* pl) { return pl ? (pl->top ? pl->top : pl)->empty_queries : 0; }
 
@@ -1454,6 +1626,7 @@ int fdes_plan_slice_loop_ms(fdes_plan* pl, double* total_ms, int64_t* slices)
     if (!live_plan(pl)) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
+    RC(gang_flush(pl));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double t = 0;
     int64_t n = 0;
@@ -1465,6 +1638,7 @@ int fdes_plan_slice_loop_ms(fdes_plan* pl, double* total_ms, int64_t* slices)
     }
     pl->ev_used = 0;
     pl->ev_done = 0;
+    pl->cfg_done = 0;
     for (fdes_plan* l : pl->lanes) {
         double tl = 0;
         int64_t nl = 0;

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
     const size_t zoff_in = (A.nbatch > 1) ? (size_t)(A.use_zin ? A.zin[bz] : bz) * A.bstride_in0 : (size_t)0;
     const size_t zoff_out = (A.nbatch > 1) ? (size_t)bz * A.bstride_out : (size_t)0;
     const cf* __restrict__ in0 = A.in0 ? reinterpret_cast<const cf*>(A.in0) + gbase + zoff_in : nullptr;
-    const cf* __restrict__ in1 = A.in1 ? reinterpret_cast<const cf*>(A.in1) + gbase : nullptr;
+    const cf* __restrict__ in1 = A.in1 ? reinterpret_cast<const cf*>(A.in1) + gbase + ((A.nbatch > 1) ? (size_t)bz * A.bstride_in1 : (size_t)0) : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
     cf* const out0 = reinterpret_cast<cf*>(A.out) + zoff_out + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0);
     if constexpr (PRE != XF_NONE || POST != XF_NONE) {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
         if constexpr (MID == MID_ATOMS) {
             // squareAtoms_d (src/crystalMaker.cu:73-123) from the (slice, species, row)-sorted records, as MID_ATOMS of
             // fft_lds.hip: tile zeroed in LDS, ONE wave adds the bilinear weights with LDS float atomics in sorted order
-            const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs);
+            const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_recs : (size_t)0);
             const int rlo = row0 > 0 ? row0 - 1 : 0;
             const int rhi = (row0 + R + 1 < A.nrows) ? row0 + R + 1 : A.nrows;
             int plo[2] = {0, 0}, phi[2] = {0, 0};
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
                 const int qb = (A.nbatch > 1) ? (comp ? A.zq1[bz] : A.zq0[bz]) : (comp ? A.q1 : A.q0);
                 const int q = qb < 0 ? -1 : qb + (int)blockIdx.y;
                 if (q >= 0) {
-                    const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
+                    const int* __restrict__ rs = A.rowstart + ((A.nbatch > 1) ? (size_t)bz * A.bstride_rowstart : (size_t)0) + (size_t)q * (size_t)(A.nrows + 1);
                     plo[comp] = rs[rlo];
                     phi[comp] = rs[rhi];
                 }

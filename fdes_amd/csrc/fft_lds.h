@@ -78,8 +78,12 @@ struct PassArgs {
     // in0 + (use_zin ? zin[z] : z) * bstride_in0 and writes out + z * bstride_out (out2 + z * bstride_out2); MID_ATOMS:
     // q0 / q1 = zq0[z] / zq1[z].  The potential / transmission passes of several slice pairs of ONE configuration run this
     // way (a single image at 1024^2 and below cannot fill the chip with one slice's rows).
+    // A gang of configurations (engine.hip) is the same launch with one CONFIGURATION per grid z: the second
+    // operand of MID_MULPSI then also moves by z (bstride_in1) and so do the atom records and their row table of MID_ATOMS
+    // (bstride_recs in records, bstride_rowstart in ints; zq0 / zq1 then hold the same slice for every z).
     int nbatch = 1, use_zin = 0;
     size_t bstride_in0 = 0, bstride_out = 0, bstride_out2 = 0;
+    size_t bstride_in1 = 0, bstride_recs = 0, bstride_rowstart = 0;
     int zin[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int zq0[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, zq1[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // diagnostic builds (-DFDES_STAMPS): per wave, 16 shader-clock stamps of the pass's phases (tools/stamps.py)

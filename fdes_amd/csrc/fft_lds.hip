@@ -400,7 +400,7 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
     const size_t zoff_in = (A.nbatch > 1) ? (size_t)(A.use_zin ? A.zin[bz] : bz) * A.bstride_in0 : (size_t)0;
     const size_t zoff_out = (A.nbatch > 1) ? (size_t)bz * A.bstride_out : (size_t)0;
     const float2* __restrict__ in0 = A.in0 ? reinterpret_cast<const float2*>(A.in0) + gbase + zoff_in : nullptr;
-    const float2* __restrict__ in1 = A.in1 ? reinterpret_cast<const float2*>(A.in1) + gbase : nullptr;
+    const float2* __restrict__ in1 = A.in1 ? reinterpret_cast<const float2*>(A.in1) + gbase + ((A.nbatch > 1) ? (size_t)bz * A.bstride_in1 : (size_t)0) : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
     float2* __restrict__ zsrc = A.zsrc ? reinterpret_cast<float2*>(A.zsrc) + gbase : nullptr;
     float2* const out0 = reinterpret_cast<float2*>(A.out) + zoff_out + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0); // MID_ATOMS: one launch covers every species
@@ -439,7 +439,7 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
         if constexpr (MID == MID_ATOMS) {
             // squareAtoms_d (src/crystalMaker.cu:73-123) without a deposit grid: the few atoms whose bilinear
             // footprint touches this row group are read from the (slice, species, row)-sorted records.
-            const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs);
+            const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_recs : (size_t)0);
             // candidate ranges of both components (4 independent loads), then the records are staged through LDS
             // (free before the first exchange) so that the walk below is not a chain of dependent global loads
             const int rlo = row0 > 0 ? row0 - 1 : 0;
@@ -450,7 +450,7 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
                 const int qb = (A.nbatch > 1) ? (comp ? A.zq1[bz] : A.zq0[bz]) : (comp ? A.q1 : A.q0);
                 const int q = qb < 0 ? -1 : qb + (int)blockIdx.y; // blockIdx.y = species
                 if (q >= 0) {
-                    const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
+                    const int* __restrict__ rs = A.rowstart + ((A.nbatch > 1) ? (size_t)bz * A.bstride_rowstart : (size_t)0) + (size_t)q * (size_t)(A.nrows + 1);
                     plo[comp] = rs[rlo];
                     phi[comp] = rs[rhi];
                 }

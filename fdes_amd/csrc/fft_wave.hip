@@ -172,7 +172,9 @@ __device__ __forceinline__ void wave_fence()
 }
 
 // one row FFT of this wave: a[l] = x[t + 64 l] on entry, X[t + 64 l] on exit
-template <int N, bool INV>
+// HX: the exchange goes through a window of HALF the size, real parts first, imaginary parts second (same LDS bytes in
+// twice as many 32-bit accesses): a row then occupies 4 N bytes of LDS and twice as many rows fit on a CU
+template <int N, bool INV, bool HX = false>
 __device__ __forceinline__ void wave_fft(cf (&a)[N / 64], cf* __restrict__ xr, const int t, const TwWave<N / 64>& tw)
 {
     constexpr int P = N / 64, NB = P / 8;
@@ -206,13 +208,7 @@ __device__ __forceinline__ void wave_fft(cf (&a)[N / 64], cf* __restrict__ xr, c
             a[c] = p + q;
             a[c + 16] = twmul_rt<INV>(p - q, w);
         }
-        // S4: element (k1 = c + 16 h, b, t1) goes to lane k1 + 32 b, register t1
-        cf* wr = xr + (t & 31) * 65 + 16 * (t >> 5);
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-            wr[c] = a[c];
-            wr[c + 32] = a[c + 16];
-        }
+        // S4: element (k1 = c + 16 h, b, t1) goes to lane k1 + 32 b, register t1 (below)
     } else if constexpr (P == 16) {
         // S3: radix-4 over the four lane quarters, t = t1 + 16 t0.  Two swap levels bring the four quarters' values of
         // k1 = c + 4 t0 (c < 4; t0 = this lane's quarter) into registers a[c + 4 g], g = quarter:
@@ -244,28 +240,42 @@ __device__ __forceinline__ void wave_fft(cf (&a)[N / 64], cf* __restrict__ xr, c
             a[c + 8] = twmul_rt<INV>(a[c + 8], w2);
             a[c + 12] = twmul_rt<INV>(a[c + 12], w3);
         }
-        // S4: element (k1 = c + 4 t0, b, t1) goes to lane k1 + 16 b, register t1
-        cf* wr = xr + (t & 15) * 65 + 4 * (t >> 4);
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) wr[c + 16 * b] = a[c + 4 * b];
-    } else {
-        cf* wr = xr + t * 65;
-#pragma unroll
-        for (int k1 = 0; k1 < P; k1++) wr[k1] = a[k1];
+        // S4: element (k1 = c + 4 t0, b, t1) goes to lane k1 + 16 b, register t1 (below)
     }
-    wave_fence();
+    // S4 / S5: register k of lane t is written to wbase + wdst(k); lane t then reads element j 65 + t into register j
+    const int wbase = (P == 32) ? (t & 31) * 65 + 16 * (t >> 5) : (P == 16) ? (t & 15) * 65 + 4 * (t >> 4) : t * 65;
+    auto wdst = [](int k) constexpr -> int { return (P == 32) ? (k < 16 ? k : k + 16) : (P == 16) ? (k & 3) + 16 * (k >> 2) : k; };
+    if constexpr (!HX) {
+        cf* wr = xr + wbase;
 #pragma unroll
-    for (int j = 0; j < P; j++) a[j] = xr[j * 65 + t];
-    wave_fence();
+        for (int k = 0; k < P; k++) wr[wdst(k)] = a[k];
+        wave_fence();
+#pragma unroll
+        for (int j = 0; j < P; j++) a[j] = xr[j * 65 + t];
+        wave_fence();
+    } else {
+        float* xf = reinterpret_cast<float*>(xr);
+        float* wr = xf + wbase;
+#pragma unroll
+        for (int k = 0; k < P; k++) wr[wdst(k)] = a[k].x;
+        wave_fence();
+#pragma unroll
+        for (int j = 0; j < P; j++) a[j].x = xf[j * 65 + t];
+        wave_fence();
+#pragma unroll
+        for (int k = 0; k < P; k++) wr[wdst(k)] = a[k].y;
+        wave_fence();
+#pragma unroll
+        for (int j = 0; j < P; j++) a[j].y = xf[j * 65 + t];
+        wave_fence();
+    }
     rP<P, INV>(a);
 }
 
-template <int N, int XF> __device__ __forceinline__ void wxform(cf (&a)[N / 64], cf* xr, int t, const TwWave<N / 64>& tw)
+template <int N, int XF, bool HX = false> __device__ __forceinline__ void wxform(cf (&a)[N / 64], cf* xr, int t, const TwWave<N / 64>& tw)
 {
-    if constexpr (XF == XF_FWD) wave_fft<N, false>(a, xr, t, tw);
-    if constexpr (XF == XF_INV) wave_fft<N, true>(a, xr, t, tw);
+    if constexpr (XF == XF_FWD) wave_fft<N, false, HX>(a, xr, t, tw);
+    if constexpr (XF == XF_INV) wave_fft<N, true, HX>(a, xr, t, tw);
 }
 
 // a[l] = row[t + 64 l]; `band`: the columns beyond the 2/3 band limit of a SQUARE grid count as zero and are not
@@ -475,14 +485,30 @@ __device__ __forceinline__ int live_cols(int i2, int md2)
 // blockIdx.x, blockIdx.x + gridDim.x, ...; the operands of the NEXT group are requested into a second register set
 // before the butterflies of the current one start, so that the CU's loads are in flight while its vector units work and
 // its stores drain while the next group is transformed (software pipeline with the register file as the landing zone).
+// Half-size LDS regions (wave_fft HX; the staged transposed store also goes re / im): 4 N bytes of LDS per row, so that
+// four workgroups = sixteen rows fit on a CU where the registers allow it (<= 128: the one-operand passes at 2048 points).
+// FDES_W_HALFX is a mask of the passes built that way: 1 = band limit (P4), 2 = propagator (P6)
+#ifndef FDES_W_HALFX
+#define FDES_W_HALFX 0
+#endif
+template <int N, int MID, bool PIPE> constexpr bool whalfx()
+{
+    return N == 2048 && !PIPE && (((FDES_W_HALFX & 1) && MID == MID_MASK) || ((FDES_W_HALFX & 2) && MID == MID_PTAB));
+}
+template <int N, int MID, bool PIPE> constexpr size_t wlds_bytes()
+{
+    return whalfx<N, MID, PIPE>() ? sizeof(float) * (size_t)WaveGeo<N>::ROWP * WaveGeo<N>::R + 64 : WaveGeo<N>::LDS_BYTES;
+}
+
 template <int N, int PRE, int MID, int POST, bool STORE_T, bool PIPE>
 __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ lds)
 {
     using G_ = WaveGeo<N>;
     constexpr int P = G_::P, R = G_::R, THR = G_::THR;
+    constexpr bool HX = whalfx<N, MID, PIPE>();
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), t = tid & 63;
-    cf* __restrict__ xr = lds + w * G_::ROWP;
+    cf* __restrict__ xr = HX ? reinterpret_cast<cf*>(reinterpret_cast<float*>(lds) + w * G_::ROWP) : lds + w * G_::ROWP;
     const int nvirt = A.nvirt > 0 ? A.nvirt : (int)gridDim.x;
     int vb = (int)blockIdx.x + (PIPE ? 0 : A.vb0);
     if (vb >= nvirt) return;
@@ -524,6 +550,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     const int bz = (int)blockIdx.z;
     const size_t zoff_in = (A.nbatch > 1) ? (size_t)(A.use_zin ? A.zin[bz] : bz) * A.bstride_in0 : (size_t)0;
     const size_t zoff_out = (A.nbatch > 1) ? (size_t)bz * A.bstride_out : (size_t)0;
+    const size_t zoff_in1 = (A.nbatch > 1) ? (size_t)bz * A.bstride_in1 : (size_t)0;
     cf* const out0 = reinterpret_cast<cf*>(A.out) + zoff_out + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0);
 
     // operands requested ahead: the row(s) of in0 / in1 and the filter values of this wave's row in the (next) group
@@ -531,7 +558,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     // (4096-point rows: two operands of 128 registers each and a third one on its way are what fits beside the temporaries;
     //  the second operand of the current group is then requested at the top of the iteration)
     constexpr bool PRE_B = (MID == MID_MULPSI) && (FDES_W_P5_PREFETCH || PIPE) && !(PIPE && N > 2048);
-    constexpr bool PV_HELD = (MID == MID_PTAB) && (FDES_W_PTAB_EARLY || PIPE) && !(PIPE && N > 2048);
+    constexpr bool PV_HELD = (MID == MID_PTAB) && (FDES_W_PTAB_EARLY || PIPE) && !(PIPE && N > 2048) && !HX;
     constexpr bool ACC = PIPE && FDES_W_ACC_PREFETCH; // look-ahead operands land in the accumulation registers
     cf an[LOADS_ROW ? P : 1];
     cf bn[PRE_B ? P : 1];
@@ -547,7 +574,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
             }
         } else {
             if constexpr (LOADS_ROW) wload_row<N>(an, reinterpret_cast<const cf*>(A.in0) + rb + zoff_in, t, (A.skip_dead_loads & 1) != 0);
-            if constexpr (PRE_B) wload_row<N>(bn, reinterpret_cast<const cf*>(A.in1) + rb, t, (A.skip_dead_loads & 2) != 0);
+            if constexpr (PRE_B) wload_row<N>(bn, reinterpret_cast<const cf*>(A.in1) + rb + zoff_in1, t, (A.skip_dead_loads & 2) != 0);
             if constexpr (MID == MID_GTAB) {
 #pragma unroll
                 for (int l = 0; l < P; l++) gn[l] = A.gtab[rb + t + 64 * l];
@@ -587,7 +614,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     const int grow = row0 + w;
     const size_t rbase = (size_t)grow * pin; // wave-uniform
     const cf* __restrict__ in0 = A.in0 ? reinterpret_cast<const cf*>(A.in0) + rbase + zoff_in : nullptr;
-    const cf* __restrict__ in1 = A.in1 ? reinterpret_cast<const cf*>(A.in1) + rbase : nullptr;
+    const cf* __restrict__ in1 = A.in1 ? reinterpret_cast<const cf*>(A.in1) + rbase + zoff_in1 : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + rbase : nullptr;
 
     cf a[P];
@@ -637,7 +664,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
             float gv[P];
 #pragma unroll
             for (int l = 0; l < P; l++) gv[l] = gtab[zo + t + 64 * l];
-            wxform<N, PRE>(a, xr, t, tw);
+            wxform<N, PRE, HX>(a, xr, t, tw);
 #pragma unroll
             for (int l = 0; l < P; l++) {
                 acc[l].x += a[l].x * gv[l];
@@ -651,7 +678,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
             // squareAtoms_d (src/crystalMaker.cu:73-123) from the (slice, species, row)-sorted records, as MID_ATOMS of
             // fft_lds.hip: the rows are zeroed in LDS (each wave its own region, natural order), ONE wave adds the bilinear
             // weights of all four rows with LDS float atomics in sorted order, every wave then picks up its row
-            const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs);
+            const AtomRec* __restrict__ recs = reinterpret_cast<const AtomRec*>(A.recs) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_recs : (size_t)0);
             const int rlo = row0 > 0 ? row0 - 1 : 0;
             const int rhi = (row0 + R + 1 < A.nrows) ? row0 + R + 1 : A.nrows;
             int plo[2] = {0, 0}, phi[2] = {0, 0};
@@ -660,7 +687,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
                 const int qb = (A.nbatch > 1) ? (comp ? A.zq1[bz] : A.zq0[bz]) : (comp ? A.q1 : A.q0);
                 const int q = qb < 0 ? -1 : qb + (int)blockIdx.y;
                 if (q >= 0) {
-                    const int* __restrict__ rs = A.rowstart + (size_t)q * (size_t)(A.nrows + 1);
+                    const int* __restrict__ rs = A.rowstart + ((A.nbatch > 1) ? (size_t)bz * A.bstride_rowstart : (size_t)0) + (size_t)q * (size_t)(A.nrows + 1);
                     plo[comp] = rs[rlo];
                     phi[comp] = rs[rhi];
                 }
@@ -712,7 +739,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
 #pragma unroll
             for (int l = 0; l < P; l++) pv[l] = pcol[t + 64 * l];
         }
-        wxform<N, PRE>(a, xr, t, tw);
+        wxform<N, PRE, HX>(a, xr, t, tw);
         if constexpr (MID == MID_EXPIV_PAIR) {
             // two slices share one potential grid (V_s = Re, V_(s+1) = Im): first slice now, the second slice's potential
             // waits as one float per pixel
@@ -750,7 +777,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
             }
         } else if constexpr (MID == MID_MULPSI) {
             if constexpr (!PRE_B && !PIPE) wload_row<N>(b, in1, t, (A.skip_dead_loads & 2) != 0);
-            wxform<N, PRE>(b, xr, t, tw);
+            wxform<N, PRE, HX>(b, xr, t, tw);
 #pragma unroll
             for (int l = 0; l < P; l++) a[l] = cmul3(a[l], b[l]); // f0 = t, f1 = psi
             if constexpr (LATE_REQ) {
@@ -771,8 +798,23 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
         } else {
             // every wave leaves its row in natural order in its own region; after the barrier all threads write R
             // contiguous elements (one 32-byte segment) per output row
+            float re[HX ? P : 1];
+            float* const ldsf = reinterpret_cast<float*>(lds);
+            const int hx_rd = (tid & (R - 1)) * G_::ROWP + tid / R;
+            if constexpr (HX) { // real parts first: staged, picked up by the threads that will store them; then the imaginary parts
+                float* xf = reinterpret_cast<float*>(xr);
 #pragma unroll
-            for (int l = 0; l < P; l++) xr[t + 64 * l] = v[l];
+                for (int l = 0; l < P; l++) xf[t + 64 * l] = v[l].x;
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < P; it++) re[it] = ldsf[hx_rd + it * 64];
+                __syncthreads();
+#pragma unroll
+                for (int l = 0; l < P; l++) xf[t + 64 * l] = v[l].y;
+            } else {
+#pragma unroll
+                for (int l = 0; l < P; l++) xr[t + 64 * l] = v[l];
+            }
             __syncthreads();
             // output element (column c, row row0 + rr) at byte offset (c ldt + rr) 8 from dst: one running 32-bit offset per
             // thread (made opaque per step: unrolled, the compiler otherwise forms P scalar row pointers and spills them)
@@ -787,7 +829,11 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
 #pragma unroll
                 for (int it = 0; it < P; it++) {
                     const bool dead = decltype(skip_dead)::value && (64 * it > N / 3) && (64 * it + 63 < N - N / 3);
-                    if (!dead) *reinterpret_cast<cf*>(dst + off) = lds[rr * G_::ROWP + c0 + it * 64];
+                    if constexpr (HX) {
+                        if (!dead) *reinterpret_cast<cf*>(dst + off) = cf{re[it], ldsf[hx_rd + it * 64]};
+                    } else {
+                        if (!dead) *reinterpret_cast<cf*>(dst + off) = lds[rr * G_::ROWP + c0 + it * 64];
+                    }
                     off += step;
                     asm volatile("" : "+v"(off));
                 }
@@ -798,7 +844,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
             else emit(std::false_type{});
         }
     };
-    wxform<N, POST>(a, xr, t, tw);
+    wxform<N, POST, HX>(a, xr, t, tw);
     store_row(a, out0);
     if constexpr (MID == MID_EXPIV_PAIR) {
 #pragma unroll
@@ -806,7 +852,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
         if constexpr (FDES_W_SINCOS_TAB) wtransmission_tab(a, A.scale, sctab);
         else wtransmission(a, A.scale);
         __syncthreads(); // every wave has read the staged tile before the regions are exchange buffers again
-        wxform<N, POST>(a, xr, t, tw);
+        wxform<N, POST, HX>(a, xr, t, tw);
         store_row(a, reinterpret_cast<cf*>(A.out2) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_out2 : (size_t)0));
     }
     if constexpr (PIPE && (STORE_T || MID == MID_ATOMS)) __syncthreads(); // the staged tile has been read: the regions are free for the next group
@@ -814,7 +860,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
 }
 
 template <int N, int PRE, int MID, int POST, bool STORE_T, bool PIPE>
-__global__ __launch_bounds__(WaveGeo<N>::THR, (N <= 1024 ? (MID == MID_GTABN ? 2 : 4) : ((N <= 2048 && !PIPE) ? 2 : 1))) void k_wpass(PassArgs A)
+__global__ __launch_bounds__(WaveGeo<N>::THR, (N <= 1024 ? (MID == MID_GTABN ? 2 : 4) : (whalfx<N, MID, PIPE>() ? 4 : ((N <= 2048 && !PIPE) ? 2 : 1)))) void k_wpass(PassArgs A)
 {
     extern __shared__ cf wlds[];
     wpass_body<N, PRE, MID, POST, STORE_T, PIPE>(A, wlds);
@@ -828,13 +874,14 @@ template <int N, int PRE, int MID, int POST, bool ST, bool PIPE> hipError_t wlau
     using G_ = WaveGeo<N>;
     static std::atomic<unsigned long long> attr_set{0}; // dynamic-LDS limit: per function and device (fft_lds.hip, launch)
     auto kern = k_wpass<N, PRE, MID, POST, ST, PIPE>;
+    constexpr size_t kLds = wlds_bytes<N, MID, PIPE>();
     int dev = 0;
     {
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
     }
     if (dev < 0 || dev >= 64 || !((attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G_::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
@@ -860,10 +907,10 @@ template <int N, int PRE, int MID, int POST, bool ST, bool PIPE> hipError_t wlau
     }
     if (a.ev_start && a.ev_stop) {
         w.ev_start = w.ev_stop = nullptr;
-        hipExtLaunchKernelGGL(kern, dim3(grid, ny, nz), dim3(G_::THR), G_::LDS_BYTES, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w);
+        hipExtLaunchKernelGGL(kern, dim3(grid, ny, nz), dim3(G_::THR), kLds, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(grid, ny, nz), dim3(G_::THR), G_::LDS_BYTES, st, w);
+    hipLaunchKernelGGL(kern, dim3(grid, ny, nz), dim3(G_::THR), kLds, st, w);
     return hipGetLastError();
 }
 

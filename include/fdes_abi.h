@@ -194,6 +194,8 @@ int fdes_plan_fft_backend(const fdes_plan* plan);
 int fdes_grid_backend(int m1, int m2, int fft_option);
 /* Configurations the plan keeps in flight at once (lanes: own HIP stream and buffers each; option "lanes"). */
 int fdes_plan_lanes(const fdes_plan* plan);
+/* Configurations of one measurement that a lane runs in lockstep, every pass one launch (option "gang"; 1: off). */
+int fdes_plan_gang(const fdes_plan* plan);
 /* Number of (sub-)slices m3 after sub-slicing; slice-propagations done so far. */
 int fdes_plan_num_slices(const fdes_plan* plan);
 int64_t fdes_plan_slices_done(const fdes_plan* plan);
@@ -210,8 +212,13 @@ int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
  *                neither transformed nor moved in the fused loop (exact: they hold zeros); 0: move everything
  *   "skip_empty" 1 (default): a slice that holds no atom has t = 1 exactly, so only its Fresnel step is run
  *                (2 passes instead of 5-6); 0: every slice goes through the full sequence like the reference
- *   "lanes"      1..4 configurations in flight at once in the fused slice loop (default 2): run_config calls are
+ *   "lanes"      1..8 configurations in flight at once in the fused slice loop (default 0: four up to 1024 x 1024 pixels,
+ *                two above, never more than the job has configurations): run_config calls are
  *                dealt round-robin to lanes, partial intensity sums are folded in end_measurement
+ *   "gang"       configurations of one measurement (frozen-phonon configurations of one tilt / defocus) whose slice
+ *                loops run in lockstep on a lane, every pass ONE launch with the configurations as grid z: fills the
+ *                chip where one grid's rows cannot (up to 1024 x 1024).  -1 auto, 0 / 1 off, 2..16.  run_config then
+ *                only queues; the work is issued when the gang is full or its results are asked for.
  *   "pass_threads"  0 auto; 256 or 512 threads x two rows per thread; 1: one row per thread, four rows per workgroup;
  *                64: one wave per row (2048- and 4096-point rows); 65: the same as a software pipeline
  *   "split"      -1 (default): a plan with one lane (single-image jobs; a plan never has more lanes than the job has

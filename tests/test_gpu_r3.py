@@ -318,3 +318,33 @@ def test_randomised_parameter_sweep_round3_kernels(oracle, seed):
     eng.close()
     ref = oracle.build_measurements(hp, at, prec="f64" if kw["frPh"] == 0 else "f32")["image"]
     check(out, ref, None, 2e-5, f"round-3 sweep {seed}: {kw}")
+
+
+@pytest.mark.parametrize("kw", [dict(m=256, m3=7, nz=2, nat=200, frPh=5, n3=2, tilt=True, beam_tilt=True),
+                                dict(m=1024, m3=5, nz=3, nat=300, frPh=4), dict(m=320, m3=6, nz=2, nat=200, frPh=4, mode=2),
+                                dict(m=512, m3=9, nz=1, nat=300, frPh=6, zfrac=0.2, mode=1)])
+def test_gang_of_configurations_does_not_change_a_bit(oracle, kw):
+    """Option "gang": the frozen-phonon configurations of a measurement run their slice loops in lockstep, every pass ONE
+    launch with the configurations as grid z (own atom records, own wave; shared tables).  Same kernels, same operands per
+    configuration: images and the summed exit wave are bit-identical to one configuration per launch for every gang size
+    (also sizes that do not divide the number of configurations), with one and two lanes, tilt series, one to three
+    species, the one-wave-per-row and the mixed-radix kernels; with skip_empty a slice is skipped only when it is empty in
+    every member, so there the results agree to rounding.  The ungrouped result equals the oracle."""
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
+    for skip in (0, 1):
+        outs = {}
+        for label, opts in (("off", dict(gang=0, lanes=1)), ("2", dict(gang=2, lanes=1)), ("3", dict(gang=3, lanes=1)),
+                            ("4 x 2 lanes", dict(gang=4, lanes=2)), ("8", dict(gang=8, lanes=1)), ("off, 2 lanes", dict(gang=0, lanes=2))):
+            eng = fdes_amd.Engine(0, skip_empty=skip, **opts)
+            r = eng.build_measurements(hp, at, want_exitwave=True)
+            outs[label] = (r["image"], r["exitwave"])
+            eng.close()
+        ref = oracle.build_measurements(hp, at, prec="f32")["image"] if kw["m"] <= 320 and skip == 0 else None
+        if ref is not None:
+            check(outs["off"][0], ref, None, 2e-4, f"gang off {kw}")
+        for label, (img, ew) in outs.items():
+            if skip == 0 and not label.endswith("lanes"):
+                assert np.array_equal(img, outs["off"][0]) and np.array_equal(ew, outs["off"][1]), (label, kw)
+            else:   # lanes add their partial sums in another order; skip_empty: see above
+                assert relerr(img, outs["off"][0]) < 2e-6 and relerr(ew, outs["off"][1]) < 2e-6, (label, kw, skip)
