@@ -357,6 +357,31 @@ def run_extras(device):
                                 "frac": round(ENGINE_BYTES_PER_PX_SLICE * px * rate / 8e12, 4)}}
     pl.close()
     eng.close()
+    # BASELINE config 4 at full size: SrTiO3 beam-tilt series, 64 tilts x 8 frozen-phonon configurations, 1024^2 wave, 40
+    # slices, every slice the full sequence; engine defaults (lanes of gangs); one untimed job, one timed job
+    hp, at = specimens.case_c4()
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(device, skip_empty=0)
+    pl = eng.plan(hp, at)
+    count = max(hp.c.frPh, 1)
+    def c4_job():
+        for k in range(hp.c.n3):
+            pl.begin_measurement(k)
+            for j in range(count):
+                pl.run_config(k, j, 1.0 / count)
+            pl.end_measurement(k)
+        pl.sync()
+        torch.cuda.synchronize()
+    c4_job()
+    t0 = time.perf_counter()
+    c4_job()
+    dt = time.perf_counter() - t0
+    img = pl.get_images()
+    out["c4"] = {"workload": f"C4 SrTiO3 9x9x20 cells ({at.n} atoms, 3 species), 1024x1024 wave, {pl.m3} slices, {hp.c.n3} tilts x {count} configurations",
+                 "value": round(hp.c.n3 * count * pl.m3 / dt, 1), "unit": "slice-propagations/s", "seconds": round(dt, 4),
+                 "lanes": pl.lanes(), "gang": pl.gang(), "finite": bool(np.isfinite(img).all())}
+    pl.close()
+    eng.close()
     # the boundary call itself with HOST buffers (fdes_build_measurements: atoms in over PCIe, plan creation, tables,
     # 8 frozen-phonon configurations of the headline specimen, detector chain, image out over PCIe): the PCIe- and
     # setup-inclusive rate, never the headline
