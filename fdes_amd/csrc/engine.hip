@@ -168,7 +168,13 @@ struct fdes_plan {
     // The buffers the passes touch hold `gang` members back to back (member 0 = the plan's own pointers).
     int gang = 1;                         // members (1: off)
     int gn = 1;                           // members of the gang being issued (pass launches: nbatch)
-    struct GangCfg { int k, j; float w; };
+    struct GangCfg { int k, j; float w; int slot; };
+    // gangs ACROSS measurements (a tilt / defocus series without frozen phonons has ONE configuration per measurement):
+    // the members then belong to different k - own incoming wave, own tilt - and add into intensity slots of their own
+    // (I holds `gang` slots back to back); only fdes_build_measurements drives it, the plan API stays one k at a time
+    bool gang_k = false;
+    std::vector<std::pair<int, int>> gfinal; // (k, slot) whose detector chain waits for the members of k to be issued
+    float* Jout = nullptr;                   // where finished images go: this plan's J, or the top plan's (lanes)
     std::vector<GangCfg> gq;              // queued configurations (all of one measurement k)
     std::vector<AtomBins> gbins;          // member views of the binning buffers
     std::vector<std::vector<int>> gseg;   // members' (slice, species) segment tables (skip_empty)
@@ -855,65 +861,114 @@ int exit_wave_post(fdes_plan* pl, int k, float weight)
     return FDES_OK;
 }
 
-// The queued configurations of this plan (all of measurement k) as ONE gang: the incoming wave once (it depends on k
-// only) and copied to the members, atoms / records per member, one slice loop with the members as grid z, the detector
-// chain per member.  A slice counts as empty (skip_empty) only when it is empty in every member: the others run the
-// full sequence on it, which is always correct (t = band-limited 1).
+// addNoiseAndMtf, src/crystalMaker.cu:579-613: the summed intensity in pl->I -> image k
+int finalize_measurement(fdes_plan* pl, int k)
+{
+    fdes_ctx* c = pl->ctx;
+    const fdes_params& p = pl->p;
+    const float alpha = 1.f / ((float)(p.m1 * p.m2));
+    HIPCHK(c, fft_exec(pl,pl->I, false, c->stream));
+    if (fabsf(p.illangle) > FLT_EPSILON) {
+        if (p.mode == 0) HIPCHK(c, k_spatial_incoherence(pl->I, pl->kp, p.defoci[k], 0, c->stream));
+        if (p.mode == 1 || p.mode == 2) HIPCHK(c, k_spatial_incoherence(pl->I, pl->kp, p.defoci[k], 1, c->stream));
+    }
+    if (p.pD > FLT_EPSILON) {
+        HIPCHK(c, k_scale(pl->I, pl->m12, alpha, c->stream));
+        HIPCHK(c, fft_exec(pl,pl->I, true, c->stream));
+        HIPCHK(c, k_noise(pl->I, pl->m12, p.pD, (uint32_t)(1 + p.n3), k, c->stream)); // seed 1 + n3, :295
+        HIPCHK(c, fft_exec(pl,pl->I, false, c->stream));
+    }
+    HIPCHK(c, k_mtf(pl->I, pl->kp, alpha, c->stream));
+    HIPCHK(c, fft_exec(pl,pl->I, true, c->stream));
+    HIPCHK(c, k_crop(pl->Jout + (size_t)k * p.n1 * p.n2, pl->I, pl->kp, c->stream));
+    return FDES_OK;
+}
+
+// The queued configurations of this plan as ONE gang: the incoming wave once per measurement k (it depends on k only;
+// members of the same k get a copy), atoms / records per member, one slice loop with the members as grid z, the detector
+// chain per member into the member's intensity slot.  The members are the configurations of one measurement - or, for a
+// series with one configuration per measurement (gang_k), measurements.  A slice counts as empty (skip_empty) only when
+// it is empty in every member: the others run the full sequence on it, which is always correct (t = band-limited 1).
 int gang_flush(fdes_plan* pl)
 {
     const int n = (int)pl->gq.size();
-    if (n == 0) return FDES_OK;
     fdes_ctx* c = pl->ctx;
-    const int k = pl->gq[0].k;
-    RC(incoming_wave(pl, k));
-    for (int g = 1; g < n; g++)
-        HIPCHK(c, hipMemcpyAsync(pl->PSI + (size_t)g * pl->m12, pl->PSI, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
-    float* const xyz0 = pl->xyzFP_d;
-    const AtomBins bins0 = pl->bins;
-    bool have_all = true;
-    for (int g = 0; g < n; g++) {
-        pl->xyzFP_d = pl->gxyzFP + (size_t)g * 3 * (size_t)pl->nAt;
-        pl->bins = pl->gbins[(size_t)g];
-        const int rc = config_atoms(pl, k, pl->gq[(size_t)g].j);
-        pl->xyzFP_d = xyz0;
-        pl->bins = bins0;
-        RC(rc);
-        pl->gseg[(size_t)g] = pl->seg_h;
-        have_all = have_all && !pl->seg_h.empty();
+    if (n > 0) {
+        float2* const psi0 = pl->PSI;
+        int rcw = FDES_OK;
+        for (int g = 0; g < n && rcw == FDES_OK; g++) {
+            float2* const mine = psi0 + (size_t)g * pl->m12;
+            if (g > 0 && pl->gq[(size_t)g].k == pl->gq[(size_t)g - 1].k) {
+                if (hipMemcpyAsync(mine, mine - pl->m12, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rcw = FDES_EGPU;
+            } else {
+                pl->PSI = mine;
+                rcw = incoming_wave(pl, pl->gq[(size_t)g].k);
+                pl->PSI = psi0;
+            }
+        }
+        RC(rcw);
+        float* const xyz0 = pl->xyzFP_d;
+        const AtomBins bins0 = pl->bins;
+        bool have_all = true;
+        for (int g = 0; g < n; g++) {
+            pl->xyzFP_d = pl->gxyzFP + (size_t)g * 3 * (size_t)pl->nAt;
+            pl->bins = pl->gbins[(size_t)g];
+            const int rc = config_atoms(pl, pl->gq[(size_t)g].k, pl->gq[(size_t)g].j);
+            pl->xyzFP_d = xyz0;
+            pl->bins = bins0;
+            RC(rc);
+            pl->gseg[(size_t)g] = pl->seg_h;
+            have_all = have_all && !pl->seg_h.empty();
+        }
+        // empty in every member <=> the SUM of the members' (monotone) segment tables does not move
+        if (have_all) {
+            pl->seg_h.assign(pl->gseg[0].size(), 0);
+            for (int g = 0; g < n; g++)
+                for (size_t i = 0; i < pl->seg_h.size(); i++) pl->seg_h[i] += pl->gseg[(size_t)g][i];
+        } else {
+            pl->seg_h.clear();
+        }
+        if (pl->ev_used == pl->evs.size()) {
+            EvPair e{};
+            HIPCHK(c, hipEventCreate(&e.a));
+            HIPCHK(c, hipEventCreate(&e.b));
+            pl->evs.push_back(e);
+        }
+        EvPair& ev = pl->evs[pl->ev_used++];
+        ev.slices = pl->p.m3 * n;
+        ev.configs = n;
+        HIPCHK(c, hipEventRecord(ev.a, c->stream));
+        pl->gn = n;
+        const int rcl = slice_loop(pl, pl->p.m3);
+        pl->gn = 1;
+        RC(rcl);
+        HIPCHK(c, hipEventRecord(ev.b, c->stream));
+        pl->slices_done += (int64_t)pl->p.m3 * n;
+        float2* const i0 = pl->I;
+        int rce = FDES_OK;
+        for (int g = 0; g < n && rce == FDES_OK; g++) {
+            pl->PSI = psi0 + (size_t)g * pl->m12;
+            pl->I = i0 + (size_t)pl->gq[(size_t)g].slot * pl->m12;
+            rce = exit_wave_post(pl, pl->gq[(size_t)g].k, pl->gq[(size_t)g].w);
+        }
+        pl->PSI = psi0;
+        pl->I = i0;
+        pl->gq.clear();
+        RC(rce);
     }
-    // empty in every member <=> the SUM of the members' (monotone) segment tables does not move
-    if (have_all) {
-        pl->seg_h.assign(pl->gseg[0].size(), 0);
-        for (int g = 0; g < n; g++)
-            for (size_t i = 0; i < pl->seg_h.size(); i++) pl->seg_h[i] += pl->gseg[(size_t)g][i];
-    } else {
-        pl->seg_h.clear();
+    // measurements whose last member has just been issued: detector chain on their slot
+    if (!pl->gfinal.empty()) {
+        float2* const i0 = pl->I;
+        int rcf = FDES_OK;
+        for (size_t q = 0; q < pl->gfinal.size() && rcf == FDES_OK; q++) {
+            pl->I = i0 + (size_t)pl->gfinal[q].second * pl->m12;
+            rcf = finalize_measurement(pl, pl->gfinal[q].first);
+        }
+        pl->I = i0;
+        pl->gfinal.clear();
+        RC(rcf);
     }
-    if (pl->ev_used == pl->evs.size()) {
-        EvPair e{};
-        HIPCHK(c, hipEventCreate(&e.a));
-        HIPCHK(c, hipEventCreate(&e.b));
-        pl->evs.push_back(e);
-    }
-    EvPair& ev = pl->evs[pl->ev_used++];
-    ev.slices = pl->p.m3 * n;
-    ev.configs = n;
-    HIPCHK(c, hipEventRecord(ev.a, c->stream));
-    pl->gn = n;
-    const int rcl = slice_loop(pl, pl->p.m3);
-    pl->gn = 1;
-    RC(rcl);
-    HIPCHK(c, hipEventRecord(ev.b, c->stream));
-    pl->slices_done += (int64_t)pl->p.m3 * n;
-    float2* const psi0 = pl->PSI;
-    int rce = FDES_OK;
-    for (int g = 0; g < n && rce == FDES_OK; g++) {
-        pl->PSI = psi0 + (size_t)g * pl->m12;
-        rce = exit_wave_post(pl, k, pl->gq[(size_t)g].w);
-    }
-    pl->PSI = psi0;
-    pl->gq.clear();
-    return rce;
+    return FDES_OK;
 }
 
 // everything queued on this plan and its lanes is issued (before anything reads or resets the sums)
@@ -995,24 +1050,46 @@ void report_progress(fdes_plan* pl, int64_t issued, int64_t total_configs, bool 
 // 25 k / 20 k; GPU_MAX_HW_QUEUES changes nothing.  tools/exp/c4_job.py, tools/exp/stream_overlap.hip.)
 // Members of a gang (configurations of ONE measurement in lockstep on a lane): only the fused loop on one stream takes
 // them, and never more than a measurement has configurations
-int plan_gang(const fdes_ctx* c, const fdes_plan* pl)
+// a job of gangs that is too small for a second lane to pay (or told to use one)
+bool gang_one_lane(const fdes_ctx* c, const fdes_plan* pl)
+{
+    if (c->lanes > 0) return c->lanes == 1;
+    const double job = (double)pl->p.n3 * (double)(pl->p.frPh > 0 ? pl->p.frPh : 1) * (double)pl->p.m3 * (double)pl->p.m1 * (double)pl->p.m2;
+    return job < 4e9;
+}
+
+int plan_gang(const fdes_ctx* c, const fdes_plan* pl, bool* across_k = nullptr)
 {
     const int count = pl->p.frPh > 0 ? pl->p.frPh : 1;
-    if (c->gang == 0 || c->gang == 1 || count < 2) return 1;
+    // what a gang is made of: the configurations of one measurement, or - a series without frozen phonons has one
+    // configuration per measurement - the measurements themselves (fdes_build_measurements drives those)
+    const bool ak = count < 2;
+    const int units = ak ? pl->p.n3 : count;
+    if (across_k) *across_k = false;
+    if (c->gang == 0 || c->gang == 1 || units < 2) return 1;
     if (c->opt_fft == 1 || !Fft2D::lds_supported(pl->p.m1, pl->p.m2)) return 1;
     if (c->split > 0 || c->batch > 1 || c->pass_threads == 65 || c->walk > 1) return 1;
     // auto (tools/bench_c4.py, SrTiO3 tilt series with 16 configurations per tilt, slice-propagations/s without a gang on
     // three lanes -> with it on two): 256^2 76 k -> 226 k with 8 members (4: 155 k, 16 on one lane: 191 k), 512^2 53 k -> 121 k
     // with 8 (4: 97 k), 800^2 22 k -> 28 k with 4 (8: 27 k), 1024^2 38 k -> 45 k with 4 (2: 40 k, 8: 40 k); from 2048^2 on one
-    // configuration's rows fill the chip.  At least two gangs per measurement, so that two lanes have work.
+    // configuration's rows fill the chip.  At least two gangs per measurement resp. series, so that two lanes have work.
+    // A second lane doubles the set-up (plan, tables, graph capture: about 13 ms at 320^2) and pays from a few 10^9
+    // pixel-slices on (tools/bench_series.py, whole boundary call: bin/dataFDES.cnf 155 ms ungrouped, 62 ms with 8 x 2
+    // lanes, 30 ms with 16 members on one lane; C4, 2 x 10^10: 45 k on two lanes against 42 k on one): small jobs get one
+    // lane and larger gangs.
     int g = c->gang;
     if (g < 0) {
         const size_t m12 = (size_t)pl->p.m1 * (size_t)pl->p.m2;
-        g = m12 <= ((size_t)1 << 18) ? 8 : (m12 <= ((size_t)1 << 20) ? 4 : 1);
-        if (count >= 4 && g > count / 2) g = count / 2;
+        if (gang_one_lane(c, pl)) g = m12 <= ((size_t)1 << 18) ? 16 : (m12 <= ((size_t)1 << 20) ? 8 : 1);
+        else {
+            g = m12 <= ((size_t)1 << 18) ? 8 : (m12 <= ((size_t)1 << 20) ? 4 : 1);
+            if (units >= 4 && g > units / 2) g = units / 2;
+        }
     }
     if (g > 16) g = 16;
-    return g < count ? g : count;
+    g = g < units ? g : units;
+    if (across_k) *across_k = ak && g > 1;
+    return g;
 }
 
 int plan_lanes(const fdes_ctx* c, const fdes_plan* pl)
@@ -1020,8 +1097,9 @@ int plan_lanes(const fdes_ctx* c, const fdes_plan* pl)
     if (c->is_lane_ctx) return 1;
     const int g = plan_gang(c, pl);
     long total = (long)pl->p.n3 * (long)(pl->p.frPh > 0 ? pl->p.frPh : 1);
-    if (g > 1) total = (long)pl->p.n3 * (((long)pl->p.frPh + g - 1) / g); // gangs in flight, not configurations
+    if (g > 1) total = pl->p.frPh >= 2 ? (long)pl->p.n3 * (((long)pl->p.frPh + g - 1) / g) : ((long)pl->p.n3 + g - 1) / g; // gangs in flight, not configurations
     if (c->lanes > 0) return g > 1 ? (int)(total < c->lanes ? total : c->lanes) : c->lanes;
+    if (g > 1 && gang_one_lane(c, pl)) return 1;
     const int by_size = (pl->fused && pl->m12 <= (size_t)1024 * 1024 && g == 1) ? 3 : 2; // (gangs: two lanes measured equal to or better than three)
     return (int)(total < by_size ? total : by_size);
 }
@@ -1241,7 +1319,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLCHK(dmalloc(c, &pl->xyz0_d, n3f));
     PLCHK(dmalloc(c, &pl->xyzTO_d, n3f));
     PLCHK(dmalloc(c, &pl->xyzK_d, n3f));
-    pl->gang = plan_gang(c, pl);
+    pl->gang = plan_gang(c, pl, &pl->gang_k);
     const size_t G = (size_t)pl->gang;
     PLCHK(dmalloc(c, &pl->xyzFP_d, n3f * G));
     pl->gxyzFP = pl->xyzFP_d;
@@ -1294,12 +1372,13 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLCHK(dmalloc(c, &pl->T, pl->m12));
     PLCHK(dmalloc(c, &pl->PSI, pl->m12 * G));
     PLCHK(dmalloc(c, &pl->P, pl->m12));
-    PLCHK(dmalloc(c, &pl->I, pl->m12));
+    PLCHK(dmalloc(c, &pl->I, pl->m12 * (pl->gang_k ? G : (size_t)1)));
     PLCHK(dmalloc(c, &pl->EW, pl->m12));
     PLCHK(dmalloc(c, &pl->J, (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3));
     PLCHK(dmalloc(c, &pl->scal, (size_t)1056)); // k_normalize_to: the sum + 1024 block partials
     PLHIP(hipMemsetAsync(pl->D, 0, sizeof(float2) * pl->m12, c->stream));
-    PLHIP(hipMemsetAsync(pl->I, 0, sizeof(float2) * pl->m12, c->stream));
+    PLHIP(hipMemsetAsync(pl->I, 0, sizeof(float2) * pl->m12 * (pl->gang_k ? G : (size_t)1), c->stream));
+    pl->Jout = pl->J;
     PLHIP(hipMemsetAsync(pl->EW, 0, sizeof(float2) * pl->m12, c->stream));
     PLHIP(hipMemsetAsync(pl->J, 0, sizeof(float) * (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3, c->stream));
     {
@@ -1467,7 +1546,10 @@ int fdes_plan_begin_measurement(fdes_plan* pl, int k)
     if (!live_plan(pl) || k < 0 || k >= pl->p.n3) return FDES_EINVAL;
     fdes_ctx* c = pl->ctx;
     HIPCHK(c, hipSetDevice(c->device));
-    if (!pl->is_lane) { RC(gang_flush_all(pl)); pl->rr = 0; }
+    if (!pl->is_lane) {
+        RC(gang_flush_all(pl));
+        if (pl->gang > 1) pl->rr = (pl->rr + (unsigned)pl->gang - 1) / (unsigned)pl->gang * (unsigned)pl->gang; // a measurement starts a new gang (on the next lane)
+    }
     HIPCHK(c, k_fill(pl->I, pl->m12, 0.f, 0.f, c->stream));
     if (pl->want_ew) HIPCHK(c, k_fill(pl->EW, pl->m12, 0.f, 0.f, c->stream));
     for (fdes_plan* l : pl->lanes) { l->want_ew = pl->want_ew; RC(fdes_plan_begin_measurement(l, k)); }
@@ -1493,7 +1575,7 @@ int fdes_plan_run_config(fdes_plan* pl, int k, int j, float weight)
     }
     if (pl->gang > 1 && pl->fused && !pl->tap_mode && owner_ctx(pl)->probe_stride <= 0) {
         if (!pl->gq.empty() && pl->gq[0].k != k) RC(gang_flush(pl));
-        pl->gq.push_back({k, j, weight});
+        pl->gq.push_back({k, j, weight, 0});
         return (int)pl->gq.size() >= pl->gang ? gang_flush(pl) : FDES_OK;
     }
     RC(incoming_wave(pl, k));
@@ -1515,28 +1597,10 @@ int fdes_plan_run_config(fdes_plan* pl, int k, int j, float weight)
 
 int fdes_plan_end_measurement(fdes_plan* pl, int k)
 {
-    // addNoiseAndMtf, src/crystalMaker.cu:579-613
     if (!live_plan(pl) || k < 0 || k >= pl->p.n3) return FDES_EINVAL;
-    fdes_ctx* c = pl->ctx;
-    const fdes_params& p = pl->p;
-    HIPCHK(c, hipSetDevice(c->device));
-    const float alpha = 1.f / ((float)(p.m1 * p.m2));
+    HIPCHK(pl->ctx, hipSetDevice(pl->ctx->device));
     RC(fold_lanes(pl));
-    HIPCHK(c, fft_exec(pl,pl->I, false, c->stream));
-    if (fabsf(p.illangle) > FLT_EPSILON) {
-        if (p.mode == 0) HIPCHK(c, k_spatial_incoherence(pl->I, pl->kp, p.defoci[k], 0, c->stream));
-        if (p.mode == 1 || p.mode == 2) HIPCHK(c, k_spatial_incoherence(pl->I, pl->kp, p.defoci[k], 1, c->stream));
-    }
-    if (p.pD > FLT_EPSILON) {
-        HIPCHK(c, k_scale(pl->I, pl->m12, alpha, c->stream));
-        HIPCHK(c, fft_exec(pl,pl->I, true, c->stream));
-        HIPCHK(c, k_noise(pl->I, pl->m12, p.pD, (uint32_t)(1 + p.n3), k, c->stream)); // seed 1 + n3, :295
-        HIPCHK(c, fft_exec(pl,pl->I, false, c->stream));
-    }
-    HIPCHK(c, k_mtf(pl->I, pl->kp, alpha, c->stream));
-    HIPCHK(c, fft_exec(pl,pl->I, true, c->stream));
-    HIPCHK(c, k_crop(pl->J + (size_t)k * p.n1 * p.n2, pl->I, pl->kp, c->stream));
-    return FDES_OK;
+    return finalize_measurement(pl, k);
 }
 
 int fdes_plan_intensity_ptr(fdes_plan* pl, void** dev_ptr, size_t* bytes)
@@ -1999,6 +2063,25 @@ int fdes_build_measurements(fdes_ctx* c, const fdes_params* p, const fdes_atoms*
     const int count = pl->p.frPh > 0 ? pl->p.frPh : 1;
     const float alpha = 1.f / ((float)count); // src/crystalMaker.cu:302-304
     int rc = FDES_OK;
+    if (pl->gang_k && !exitwave) {
+        // a series with one configuration per measurement: blocks of `gang` measurements are dealt to the lanes, each block
+        // one gang (own incoming wave, tilt and intensity slot per member), its images finished behind it on that lane
+        const int G = pl->gang, nl = (int)pl->lanes.size() + 1;
+        for (fdes_plan* l : pl->lanes) l->Jout = pl->J;
+        for (int k0 = 0, b = 0; k0 < pl->p.n3 && rc == FDES_OK; k0 += G, b++) {
+            fdes_plan* lp = (b % nl) ? pl->lanes[(size_t)(b % nl) - 1] : pl;
+            const int k1 = k0 + G < pl->p.n3 ? k0 + G : pl->p.n3;
+            for (int k = k0; k < k1 && rc == FDES_OK; k++) {
+                if (k_fill(lp->I + (size_t)(k - k0) * lp->m12, lp->m12, 0.f, 0.f, lp->ctx->stream) != hipSuccess) { c->err = "k_fill"; rc = FDES_EGPU; }
+                lp->gq.push_back({k, 0, alpha, k - k0});
+                lp->gfinal.push_back({k, k - k0});
+            }
+            if (rc == FDES_OK) rc = gang_flush(lp);
+            if (rc != FDES_OK && lp != pl) c->err = "lane: " + lp->ctx->err;
+            if (rc == FDES_OK) report_progress(pl, (int64_t)k1, (int64_t)pl->p.n3, false);
+        }
+        if (rc == FDES_OK) rc = fdes_plan_sync(pl);
+    } else
     for (int k = 0; k < pl->p.n3 && rc == FDES_OK; k++) {
         rc = fdes_plan_begin_measurement(pl, k);
         for (int j = 0; j < count && rc == FDES_OK; j++) {

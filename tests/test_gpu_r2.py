@@ -277,11 +277,11 @@ def test_options_set_after_plan_creation_reach_every_lane(oracle):
         pl.end_measurement(0)
         return pl.get_images()
 
-    a = fdes_amd.Engine(0, seed=7, skip_empty=0, band_skip=0)
+    a = fdes_amd.Engine(0, seed=7, skip_empty=0, band_skip=0, lanes=2)   # (a job this small would get one lane of gangs)
     pa = a.plan(hp, at)
     assert pa.lanes() >= 2
     ref = run(a, pa)
-    b = fdes_amd.Engine(0)           # defaults: seed 1, skip_empty 1, band_skip 1
+    b = fdes_amd.Engine(0, lanes=2)  # defaults: seed 1, skip_empty 1, band_skip 1
     pb = b.plan(hp, at)
     first = run(b, pb)
     for k, v in (("seed", 7), ("skip_empty", 0), ("band_skip", 0)):

@@ -348,3 +348,31 @@ def test_gang_of_configurations_does_not_change_a_bit(oracle, kw):
                 assert np.array_equal(img, outs["off"][0]) and np.array_equal(ew, outs["off"][1]), (label, kw)
             else:   # lanes add their partial sums in another order; skip_empty: see above
                 assert relerr(img, outs["off"][0]) < 2e-6 and relerr(ew, outs["off"][1]) < 2e-6, (label, kw, skip)
+
+
+@pytest.mark.parametrize("kw", [dict(m=256, m3=7, nz=2, nat=200, n3=7, tilt=True, beam_tilt=True), dict(m=320, m3=5, nz=2, nat=150, n3=5, tilt=True, pD=50.0),
+                                dict(m=1024, m3=4, nz=1, nat=300, n3=4, tilt=True), dict(m=512, m3=9, nz=3, nat=300, n3=9, tilt=True, zfrac=0.2, mode=2),
+                                dict(m=256, m3=5, nz=2, nat=150, n3=6, mode=1, beam_tilt=True)])
+def test_gang_across_measurements_does_not_change_a_bit(oracle, kw):
+    """A series with ONE configuration per measurement (tilt / defocus series without frozen phonons - the reference's own
+    example, bin/dataFDES.cnf: 25 tilts): fdes_build_measurements runs `gang` measurements in lockstep, each member with its
+    own tilt, incoming wave and intensity slot, the detector chain (incoherence, dose noise, MTF, crop) per slot behind the
+    gang.  Images bit-identical to one measurement at a time for every gang size (also sizes that do not divide the series)
+    on one lane, equal to rounding on two (skip_empty: a slice is skipped only when it is empty in every member); the
+    ungrouped result equals the oracle."""
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
+    for skip in (0, 1):
+        outs = {}
+        for label, opts in (("off", dict(gang=0, lanes=1)), ("2", dict(gang=2, lanes=1)), ("3", dict(gang=3, lanes=1)),
+                            ("4 x 2 lanes", dict(gang=4, lanes=2)), ("8", dict(gang=8, lanes=1)), ("auto", dict())):
+            eng = fdes_amd.Engine(0, skip_empty=skip, **opts)
+            outs[label] = eng.build_measurements(hp, at)["image"]
+            eng.close()
+        if kw["m"] <= 320 and skip == 0 and not kw.get("pD"):
+            check(outs["off"], oracle.build_measurements(hp, at, prec="f32")["image"], None, 2e-4, f"series, gang off {kw}")
+        for label, img in outs.items():
+            if skip == 0:
+                assert np.array_equal(img, outs["off"]), (label, kw)
+            else:
+                assert relerr(img, outs["off"]) < 2e-6, (label, kw, skip)
