@@ -307,7 +307,7 @@ int ensure_tilt(fdes_plan* pl, int k)
 }
 
 // src/crystalMaker.cu:335-337 + the per-configuration (slice, species) binning
-int config_atoms(fdes_plan* pl, int k, int j)
+int config_atoms(fdes_plan* pl, int k, int j, bool query = true)
 {
     fdes_ctx* c = pl->ctx;
     RC(ensure_tilt(pl, k));
@@ -317,6 +317,7 @@ int config_atoms(fdes_plan* pl, int k, int j)
         HIPCHK(c, hipMemcpyAsync(pl->xyzFP_d, pl->xyzK_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, c->stream));
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
     HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, pl->fused || owner_ctx(pl)->deterministic, c->stream));
+    if (!query) return FDES_OK; // (a gang asks once for all its members, gang_flush)
     fdes_plan* tp = pl->top ? pl->top : pl;
     constexpr int kDenseAfter = 8, kDenseRecheck = 64;
     bool ask = pl->fused && owner_ctx(pl)->skip_empty;
@@ -909,16 +910,38 @@ int gang_flush(fdes_plan* pl)
         RC(rcw);
         float* const xyz0 = pl->xyzFP_d;
         const AtomBins bins0 = pl->bins;
-        bool have_all = true;
         for (int g = 0; g < n; g++) {
             pl->xyzFP_d = pl->gxyzFP + (size_t)g * 3 * (size_t)pl->nAt;
             pl->bins = pl->gbins[(size_t)g];
-            const int rc = config_atoms(pl, pl->gq[(size_t)g].k, pl->gq[(size_t)g].j);
+            const int rc = config_atoms(pl, pl->gq[(size_t)g].k, pl->gq[(size_t)g].j, false);
             pl->xyzFP_d = xyz0;
             pl->bins = bins0;
             RC(rc);
-            pl->gseg[(size_t)g] = pl->seg_h;
-            have_all = have_all && !pl->seg_h.empty();
+        }
+        // which slices hold atoms: one question (n small copies, ONE host wait) for the whole gang; the rules of
+        // config_atoms for when a dense specimen is no longer asked, counted per member
+        bool have_all = false;
+        {
+            fdes_plan* tp = pl->top ? pl->top : pl;
+            constexpr int kDenseAfter = 8, kDenseRecheck = 64;
+            bool ask = owner_ctx(pl)->skip_empty != 0;
+            if (ask && tp->dense_streak >= kDenseAfter && (tp->cfg_seen % kDenseRecheck) >= n) ask = false;
+            tp->cfg_seen += n;
+            if (ask) {
+                const size_t len = (size_t)pl->p.m3 * pl->nZ + 1;
+                for (int g = 0; g < n; g++) {
+                    pl->gseg[(size_t)g].resize(len);
+                    HIPCHK(c, hipMemcpyAsync(pl->gseg[(size_t)g].data(), pl->gbins[(size_t)g].seg, sizeof(int) * len, hipMemcpyDeviceToHost, c->stream));
+                }
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                tp->empty_queries++;
+                for (int g = 0; g < n; g++) {
+                    bool any_empty = false;
+                    for (int q = 0; q < pl->p.m3 && !any_empty; q++) any_empty = pl->gseg[(size_t)g][(size_t)(q + 1) * pl->nZ] == pl->gseg[(size_t)g][(size_t)q * pl->nZ];
+                    tp->dense_streak = any_empty ? 0 : tp->dense_streak + 1;
+                }
+                have_all = true;
+            }
         }
         // empty in every member <=> the SUM of the members' (monotone) segment tables does not move
         if (have_all) {

@@ -325,7 +325,7 @@ def test_dense_specimen_stops_asking_for_empty_slices(oracle):
     decision, equal to the full sequence within rounding)."""
     hp, at = S.case_tiny(m=256, m3=6, nz=2, frPh=24, nat=900, zfrac=0.5, seed=5)
     fdes_amd.consistent(hp)
-    eng = fdes_amd.Engine(0, lanes=1, split=0)
+    eng = fdes_amd.Engine(0, lanes=1, split=0, gang=0)   # (a gang asks once for all its members: below)
     pl = eng.plan(hp, at)
     first = pl.tap_wave(0, 3)
     pl.begin_measurement(0)
@@ -337,12 +337,20 @@ def test_dense_specimen_stops_asking_for_empty_slices(oracle):
     assert np.array_equal(first.view(np.float32), late.view(np.float32))
     assert relerr(late, oracle.wave(oracle.sub_sliced(hp)[0], at, 0, 3, prec="f64")) < 2e-5
     pl.close(); eng.close()
+    eng = fdes_amd.Engine(0, lanes=1, gang=8)            # 20 configurations = gangs of 8, 8, 4: one question per gang,
+    pl = eng.plan(hp, at)                                # none once eight members in a row had no empty slice
+    pl.begin_measurement(0)
+    for j in range(20):
+        pl.run_config(0, j, 1.0 / 20)
+    pl.sync()
+    assert pl.gang() == 8 and pl.empty_queries() == 1
+    pl.close(); eng.close()
     # a specimen with vacuum above and below: every configuration is asked, the short cut keeps being taken
     hp2, at2 = S.case_tiny(m=256, m3=12, nz=2, frPh=24, nat=300, zfrac=0.2, seed=6)
     fdes_amd.consistent(hp2)
     waves = []
     for skip in (1, 0):
-        eng = fdes_amd.Engine(0, lanes=1, split=0, skip_empty=skip)
+        eng = fdes_amd.Engine(0, lanes=1, split=0, skip_empty=skip, gang=0)
         pl = eng.plan(hp2, at2)
         pl.begin_measurement(0)
         for j in range(12):
