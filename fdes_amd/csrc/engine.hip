@@ -172,6 +172,8 @@ struct fdes_plan {
     // gangs ACROSS measurements (a tilt / defocus series without frozen phonons has ONE configuration per measurement):
     // the members then belong to different k - own incoming wave, own tilt - and add into intensity slots of their own
     // (I holds `gang` slots back to back); only fdes_build_measurements drives it, the plan API stays one k at a time
+    bool one_shot_few = false;  // fdes_build_measurements: this plan lives for one job that replays its slice loop fewer than four
+                                // times per lane - capturing and instantiating a graph (2.3 ms for 600 nodes) costs more than it saves
     bool gang_k = false;
     std::vector<std::pair<int, int>> gfinal; // (k, slot) whose detector chain waits for the members of k to be issued
     float* Jout = nullptr;                   // where finished images go: this plan's J, or the top plan's (lanes)
@@ -179,6 +181,7 @@ struct fdes_plan {
     std::vector<AtomBins> gbins;          // member views of the binning buffers
     std::vector<std::vector<int>> gseg;   // members' (slice, species) segment tables (skip_empty)
     float* gxyzFP = nullptr;              // [gang][3 nAt] jittered coordinates (member 0 = xyzFP_d)
+    float2* gscr = nullptr;               // [gang][m12] scratch of the members' 2-D transforms outside the slice loop
     std::vector<void*> gang_owned;        // per-member binning arrays of members >= 1
     size_t recs_stride = 0, rowstart_stride = 0;
     float2* peer_stage = nullptr;   // landing buffer for another GPU's partial sum (fdes_plan_accumulate_from)
@@ -772,7 +775,7 @@ int slice_loop(fdes_plan* pl, int nslices)
     };
     const bool timing_probe = (oc->probe_stride > 0);
     // the two-stream loop is issued directly: captured, its cross-stream edges cost 5 % (12.2 k against 12.85 k)
-    if (!oc->opt_graph || timing_probe || nslices < 1 || (pl->fused && pl->split)) return issue();
+    if (!oc->opt_graph || timing_probe || nslices < 1 || (pl->fused && pl->split) || (pl->top ? pl->top : pl)->one_shot_few) return issue();
     // key: slice count, band option and the empty-slice pattern (FNV-1a over one bit per slice)
     uint64_t key = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
@@ -885,6 +888,96 @@ int finalize_measurement(fdes_plan* pl, int k)
     return FDES_OK;
 }
 
+// 2-D transforms of n grids `stride` elements apart: with the hand-written back-end the two passes take the grids as grid z
+int fft_gang(fdes_plan* pl, float2* data, int n, size_t stride, bool inverse)
+{
+    fdes_ctx* c = pl->ctx;
+    if (n <= 1 || pl->fft->backend != 2 || !pl->gscr) {
+        for (int g = 0; g < n; g++) HIPCHK(c, fft_exec(pl, data + (size_t)g * stride, inverse, c->stream));
+        return FDES_OK;
+    }
+    const int xf = inverse ? XF_INV : XF_FWD;
+    PassArgs a;
+    a.in0 = data; a.out = pl->gscr; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.nrows = pl->p.m2; a.wg = pl->fft->wg;
+    a.nbatch = n; a.bstride_in0 = stride; a.bstride_out = pl->m12;
+    HIPCHK(c, lds_pass(pl->p.m1, xf, MID_NONE, XF_NONE, true, a, c->stream));
+    PassArgs b;
+    b.in0 = pl->gscr; b.out = data; b.tw0 = pl->fft->tw0y; b.tw1 = pl->fft->tw1y; b.nrows = pl->p.m1; b.wg = pl->fft->wg;
+    b.nbatch = n; b.bstride_in0 = pl->m12; b.bstride_out = stride;
+    HIPCHK(c, lds_pass(pl->p.m2, xf, MID_NONE, XF_NONE, true, b, c->stream));
+    return FDES_OK;
+}
+
+// exit_wave_post of the n members of a gang (waves back to back in PSI) as six launches: imaging mode without an
+// exit-wave output; the other cases go member by member
+int exit_wave_post_gang(fdes_plan* pl, int n)
+{
+    fdes_ctx* c = pl->ctx;
+    const fdes_params& p = pl->p;
+    if (n <= 1 || p.mode != 0 || pl->want_ew || !pl->gscr) {
+        float2* const psi0 = pl->PSI;
+        float2* const i0 = pl->I;
+        int rce = FDES_OK;
+        for (int g = 0; g < n && rce == FDES_OK; g++) {
+            pl->PSI = psi0 + (size_t)g * pl->m12;
+            pl->I = i0 + (size_t)pl->gq[(size_t)g].slot * pl->m12;
+            rce = exit_wave_post(pl, pl->gq[(size_t)g].k, pl->gq[(size_t)g].w);
+        }
+        pl->PSI = psi0;
+        pl->I = i0;
+        return rce;
+    }
+    GangPar dk, wt;
+    dk.n = wt.n = n;
+    for (int g = 0; g < n; g++) {
+        dk.f[g] = p.defoci[pl->gq[(size_t)g].k];
+        wt.f[g] = pl->gq[(size_t)g].w;
+        wt.k[g] = pl->gq[(size_t)g].slot;
+    }
+    RC(fft_gang(pl, pl->PSI, n, pl->m12, false));
+    HIPCHK(c, k_lens_gang(pl->PSI, pl->m12, pl->kp, dk, c->stream));
+    RC(fft_gang(pl, pl->PSI, n, pl->m12, true));
+    HIPCHK(c, k_intensity_gang(pl->I, pl->PSI, pl->m12, 1.f / ((float)pl->m12), wt, c->stream));
+    return FDES_OK;
+}
+
+// finalize_measurement of the measurements in gfinal when their slots are 0, 1, 2 ... in order (what
+// fdes_build_measurements queues): the detector chain over all slots per launch
+int finalize_gang(fdes_plan* pl)
+{
+    fdes_ctx* c = pl->ctx;
+    const fdes_params& p = pl->p;
+    const int n = (int)pl->gfinal.size();
+    bool in_order = n > 1 && n <= 16 && pl->gscr != nullptr;
+    for (int q = 0; q < n && in_order; q++) in_order = pl->gfinal[(size_t)q].second == q;
+    if (!in_order) {
+        float2* const i0 = pl->I;
+        int rcf = FDES_OK;
+        for (size_t q = 0; q < pl->gfinal.size() && rcf == FDES_OK; q++) {
+            pl->I = i0 + (size_t)pl->gfinal[q].second * pl->m12;
+            rcf = finalize_measurement(pl, pl->gfinal[q].first);
+        }
+        pl->I = i0;
+        return rcf;
+    }
+    GangPar dk, kk;
+    dk.n = kk.n = n;
+    for (int q = 0; q < n; q++) { dk.f[q] = p.defoci[pl->gfinal[(size_t)q].first]; kk.k[q] = pl->gfinal[(size_t)q].first; }
+    const float alpha = 1.f / ((float)(p.m1 * p.m2));
+    RC(fft_gang(pl, pl->I, n, pl->m12, false));
+    if (fabsf(p.illangle) > FLT_EPSILON) HIPCHK(c, k_spatial_incoherence_gang(pl->I, pl->m12, pl->kp, p.mode == 0 ? 0 : 1, dk, c->stream));
+    if (p.pD > FLT_EPSILON) {
+        HIPCHK(c, k_scale(pl->I, pl->m12 * (size_t)n, alpha, c->stream));
+        RC(fft_gang(pl, pl->I, n, pl->m12, true));
+        HIPCHK(c, k_noise_gang(pl->I, pl->m12, pl->m12, p.pD, (uint32_t)(1 + p.n3), kk, c->stream));
+        RC(fft_gang(pl, pl->I, n, pl->m12, false));
+    }
+    HIPCHK(c, k_mtf_gang(pl->I, pl->m12, n, pl->kp, alpha, c->stream));
+    RC(fft_gang(pl, pl->I, n, pl->m12, true));
+    HIPCHK(c, k_crop_gang(pl->Jout, pl->I, pl->m12, pl->kp, kk, c->stream));
+    return FDES_OK;
+}
+
 // The queued configurations of this plan as ONE gang: the incoming wave once per measurement k (it depends on k only;
 // members of the same k get a copy), atoms / records per member, one slice loop with the members as grid z, the detector
 // chain per member into the member's intensity slot.  The members are the configurations of one measurement - or, for a
@@ -967,27 +1060,13 @@ int gang_flush(fdes_plan* pl)
         RC(rcl);
         HIPCHK(c, hipEventRecord(ev.b, c->stream));
         pl->slices_done += (int64_t)pl->p.m3 * n;
-        float2* const i0 = pl->I;
-        int rce = FDES_OK;
-        for (int g = 0; g < n && rce == FDES_OK; g++) {
-            pl->PSI = psi0 + (size_t)g * pl->m12;
-            pl->I = i0 + (size_t)pl->gq[(size_t)g].slot * pl->m12;
-            rce = exit_wave_post(pl, pl->gq[(size_t)g].k, pl->gq[(size_t)g].w);
-        }
-        pl->PSI = psi0;
-        pl->I = i0;
+        const int rce = exit_wave_post_gang(pl, n);
         pl->gq.clear();
         RC(rce);
     }
     // measurements whose last member has just been issued: detector chain on their slot
     if (!pl->gfinal.empty()) {
-        float2* const i0 = pl->I;
-        int rcf = FDES_OK;
-        for (size_t q = 0; q < pl->gfinal.size() && rcf == FDES_OK; q++) {
-            pl->I = i0 + (size_t)pl->gfinal[q].second * pl->m12;
-            rcf = finalize_measurement(pl, pl->gfinal[q].first);
-        }
-        pl->I = i0;
+        const int rcf = finalize_gang(pl);
         pl->gfinal.clear();
         RC(rcf);
     }
@@ -1078,7 +1157,7 @@ bool gang_one_lane(const fdes_ctx* c, const fdes_plan* pl)
 {
     if (c->lanes > 0) return c->lanes == 1;
     const double job = (double)pl->p.n3 * (double)(pl->p.frPh > 0 ? pl->p.frPh : 1) * (double)pl->p.m3 * (double)pl->p.m1 * (double)pl->p.m2;
-    return job < 4e9;
+    return job < 2e9;
 }
 
 int plan_gang(const fdes_ctx* c, const fdes_plan* pl, bool* across_k = nullptr)
@@ -1394,6 +1473,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLCHK(dmalloc(c, &pl->VH, pl->m12));
     PLCHK(dmalloc(c, &pl->T, pl->m12));
     PLCHK(dmalloc(c, &pl->PSI, pl->m12 * G));
+    if (G > 1) { PLCHK(dmalloc(c, &pl->gscr, pl->m12 * G)); pl->gang_owned.push_back(pl->gscr); }
     PLCHK(dmalloc(c, &pl->P, pl->m12));
     PLCHK(dmalloc(c, &pl->I, pl->m12 * (pl->gang_k ? G : (size_t)1)));
     PLCHK(dmalloc(c, &pl->EW, pl->m12));
@@ -2085,6 +2165,11 @@ int fdes_build_measurements(fdes_ctx* c, const fdes_params* p, const fdes_atoms*
     pl->want_ew = exitwave != nullptr;
     const int count = pl->p.frPh > 0 ? pl->p.frPh : 1;
     const float alpha = 1.f / ((float)count); // src/crystalMaker.cu:302-304
+    {   // slice loops this job issues per lane: configurations, or gangs of them
+        const long nl = (long)pl->lanes.size() + 1, g = pl->gang > 1 ? pl->gang : 1;
+        const long loops = (pl->gang_k && !exitwave) ? ((long)pl->p.n3 + g - 1) / g : (long)pl->p.n3 * ((count + (pl->gang_k ? 1 : g) - 1) / (pl->gang_k ? 1 : g));
+        pl->one_shot_few = (loops + nl - 1) / nl < 4;
+    }
     int rc = FDES_OK;
     if (pl->gang_k && !exitwave) {
         // a series with one configuration per measurement: blocks of `gang` measurements are dealt to the lanes, each block

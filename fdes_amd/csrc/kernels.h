@@ -8,6 +8,8 @@
 
 namespace fdes {
 
+struct GangPar { int n = 0; float f[16] = {}; int k[16] = {}; }; // per-member scalar / index of a gang launch (n = 0: none)
+
 // Scalars the reference's kernels dereference from a device-resident params_t on every launch
 // (SURVEY 8a a21); here they travel by value in the kernel argument segment.
 struct KP {
@@ -40,6 +42,14 @@ hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_
 hipError_t k_build_propagator_1d(float2* px, float2* py, const KP& p, int npow, hipStream_t st);
 hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, int pitch, hipStream_t st);
 hipError_t k_lens(float2* psi, const KP& p, float defocus_k, hipStream_t st);
+// Gang launches (engine.hip): the same point-wise kernels over the members of a gang in ONE launch (grid.y =
+// member, the member's grid `stride` elements further); per-member scalars / indices travel in GangPar.
+hipError_t k_lens_gang(float2* psi, size_t stride, const KP& p, const GangPar& gp, hipStream_t st);                 // f = defocus
+hipError_t k_intensity_gang(float2* I, const float2* psi, size_t n, float pre, const GangPar& gp, hipStream_t st);  // f = weight, k = slot of I
+hipError_t k_spatial_incoherence_gang(float2* f, size_t stride, const KP& p, int dp, const GangPar& gp, hipStream_t st); // f = defocus
+hipError_t k_mtf_gang(float2* f, size_t stride, int members, const KP& p, float alpha, hipStream_t st);
+hipError_t k_noise_gang(float2* f, size_t stride, size_t n, float dose, uint32_t seed, const GangPar& gp, hipStream_t st); // k = measurement
+hipError_t k_crop_gang(float* J, const float2* I, size_t stride, const KP& p, const GangPar& gp, hipStream_t st);   // k = image of the stack
 hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre_scale, float alpha, hipStream_t st);
 hipError_t k_tilt_beam(float2* psi, const KP& p, float tb0, float tb1, int flag, hipStream_t st);
 hipError_t k_tukey(float2* psi, const KP& p, hipStream_t st);

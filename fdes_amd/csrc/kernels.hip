@@ -261,8 +261,11 @@ __global__ void kk_propagator_1d(float2* __restrict__ px, float2* __restrict__ p
 }
 
 // ---- multiplyLensFunction (src/multisliceSimulation.cu:277-343) --------------------------------
-__global__ void kk_lens(float2* __restrict__ psi, KP p, float defocus_k)
+// (gang launches, kernels.h: blockIdx.y = member, its grid `gstride` elements further, its scalar in gp)
+__global__ void kk_lens(float2* __restrict__ psi, KP p, float defocus_k, size_t gstride, GangPar gp)
 {
+    psi += (size_t)blockIdx.y * gstride;
+    if (gp.n) defocus_k = gp.f[blockIdx.y];
     const size_t n = (size_t)p.m1 * p.m2;
     const fdes_aberration ab = p.ab;
     GS_LOOP(i, n)
@@ -305,18 +308,33 @@ __global__ void kk_lens(float2* __restrict__ psi, KP p, float defocus_k)
 // ---- cublasCsscal(1/m12) of applyLensFunction (:621) / sqrt(1/m12) of diffractionPattern
 // (src/crystalMaker.cu:716) + intensityValues (src/multisliceSimulation.cu:346-359) + cublasCaxpy
 // into the running sum (src/crystalMaker.cu:353,359,365) -----------------------------------------
+// (roundings pinned - which product of the sum of squares gets fused is otherwise the compiler's choice per kernel, and the
+//  gang kernel below must add exactly what this one adds)
+__device__ __forceinline__ float2 intensity_add(float2 a, float2 v, float pre, float alpha)
+{
+    v.x = __fmul_rn(v.x, pre);
+    v.y = __fmul_rn(v.y, pre);
+    const float q = __fmaf_rn(v.x, v.x, __fmul_rn(v.y, v.y));
+    a.x = __fmaf_rn(alpha, q, a.x);
+    a.y = __fmaf_rn(alpha, 0.f, a.y);
+    return a;
+}
 __global__ void kk_intensity_axpy(float2* __restrict__ I, const float2* __restrict__ psi, size_t n, float pre, float alpha)
+{
+    GS_LOOP(i, n) I[i] = intensity_add(I[i], psi[i], pre, alpha);
+}
+
+// the same for the members of a gang in ONE launch: member g adds into slot gp.k[g] of I; a thread owns a pixel and goes
+// through the members in order, so members that share a slot (the configurations of one measurement) add exactly as
+// their separate launches did
+__global__ void kk_intensity_gang(float2* __restrict__ I, const float2* __restrict__ psi, size_t n, float pre, GangPar gp)
 {
     GS_LOOP(i, n)
     {
-        float2 v = psi[i];
-        v.x *= pre;
-        v.y *= pre;
-        const float q = v.x * v.x + v.y * v.y;
-        float2 a = I[i];
-        a.x += alpha * q;
-        a.y += alpha * 0.f;
-        I[i] = a;
+        for (int g = 0; g < gp.n; g++) {
+            float2* dst = I + (size_t)gp.k[g] * n + i;
+            *dst = intensity_add(*dst, psi[(size_t)g * n + i], pre, gp.f[g]);
+        }
     }
 }
 
@@ -393,8 +411,10 @@ __global__ void kk_mask_filter(float2* __restrict__ psi, KP p)
 }
 
 // ---- multiplySpatialIncoherence / ...DP (src/multisliceSimulation.cu:391-442) -------------------
-__global__ void kk_spatial(float2* __restrict__ f, KP p, float defocus_k, int dp)
+__global__ void kk_spatial(float2* __restrict__ f, KP p, float defocus_k, int dp, size_t gstride, GangPar gp)
 {
+    f += (size_t)blockIdx.y * gstride;
+    if (gp.n) defocus_k = gp.f[blockIdx.y];
     const size_t n = (size_t)p.m1 * p.m2;
     GS_LOOP(i, n)
     {
@@ -422,8 +442,9 @@ __global__ void kk_spatial(float2* __restrict__ f, KP p, float defocus_k, int dp
 }
 
 // ---- multiplyMtf (src/multisliceSimulation.cu:362-388) + the cublasCsscal after it (crystalMaker.cu:609)
-__global__ void kk_mtf(float2* __restrict__ f, KP p, float alpha)
+__global__ void kk_mtf(float2* __restrict__ f, KP p, float alpha, size_t gstride)
 {
+    f += (size_t)blockIdx.y * gstride;
     const size_t n = (size_t)p.m1 * p.m2;
     GS_LOOP(i, n)
     {
@@ -443,8 +464,10 @@ __global__ void kk_mtf(float2* __restrict__ f, KP p, float alpha)
 }
 
 // ---- ascombeNoise_d (src/crystalMaker.cu:50-70); deviates from Philox stream 1, key (seed, k, pixel)
-__global__ void kk_noise(float2* __restrict__ f, size_t n, float dose, uint32_t seed, uint32_t k)
+__global__ void kk_noise(float2* __restrict__ f, size_t n, float dose, uint32_t seed, uint32_t k, size_t gstride, GangPar gp)
 {
+    f += (size_t)blockIdx.y * gstride;
+    if (gp.n) k = (uint32_t)gp.k[blockIdx.y];
     GS_LOOP(i, n)
     {
         float2 v = f[i];
@@ -462,9 +485,11 @@ __global__ void kk_noise(float2* __restrict__ f, size_t n, float dose, uint32_t 
 }
 
 // ---- copyMiddleOut (src/optimFunctions.cu:109-121) ---------------------------------------------
-__global__ void kk_crop(float* __restrict__ J, const float2* __restrict__ I, KP p)
+__global__ void kk_crop(float* __restrict__ J, const float2* __restrict__ I, KP p, size_t gstride, GangPar gp)
 {
     const size_t n = (size_t)p.n1 * p.n2;
+    I += (size_t)blockIdx.y * gstride;
+    if (gp.n) J += (size_t)gp.k[blockIdx.y] * n; // image gp.k[member] of the stack
     GS_LOOP(j, n)
     {
         const int i1 = (int)(j % (size_t)p.n1), i2 = (int)(j / (size_t)p.n1);
@@ -535,7 +560,21 @@ hipError_t k_mul(float2* dst, const float2* f0, const float2* f1, size_t n, hipS
 hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_t st) { LAUNCH(kk_propagator, (size_t)p.m1 * p.m2, st, P, p, transposed); }
 hipError_t k_build_propagator_1d(float2* px, float2* py, const KP& p, int npow, hipStream_t st) { LAUNCH(kk_propagator_1d, (size_t)p.m1 + p.m2, st, px, py, p, npow); }
 hipError_t k_build_gtab(float* G, const KP& p, const Kirk& kz, int transposed, int pitch, hipStream_t st) { LAUNCH(kk_gtab, (size_t)p.m1 * p.m2, st, G, p, kz, transposed, pitch); }
-hipError_t k_lens(float2* psi, const KP& p, float dk, hipStream_t st) { LAUNCH(kk_lens, (size_t)p.m1 * p.m2, st, psi, p, dk); }
+hipError_t k_lens(float2* psi, const KP& p, float dk, hipStream_t st) { LAUNCH(kk_lens, (size_t)p.m1 * p.m2, st, psi, p, dk, (size_t)0, GangPar{}); }
+// gang launches: grid.y = member
+#define LAUNCH_G(kern, n, members, st, ...)                                     \
+    do {                                                                        \
+        dim3 g_ = grid_for(n);                                                  \
+        g_.y = (unsigned)(members);                                             \
+        hipLaunchKernelGGL(kern, g_, dim3(256), 0, st, __VA_ARGS__);            \
+        return hipGetLastError();                                               \
+    } while (0)
+hipError_t k_lens_gang(float2* psi, size_t stride, const KP& p, const GangPar& gp, hipStream_t st) { LAUNCH_G(kk_lens, (size_t)p.m1 * p.m2, gp.n, st, psi, p, 0.f, stride, gp); }
+hipError_t k_intensity_gang(float2* I, const float2* psi, size_t n, float pre, const GangPar& gp, hipStream_t st) { LAUNCH(kk_intensity_gang, n, st, I, psi, n, pre, gp); }
+hipError_t k_spatial_incoherence_gang(float2* f, size_t stride, const KP& p, int dp, const GangPar& gp, hipStream_t st) { LAUNCH_G(kk_spatial, (size_t)p.m1 * p.m2, gp.n, st, f, p, 0.f, dp, stride, gp); }
+hipError_t k_mtf_gang(float2* f, size_t stride, int members, const KP& p, float alpha, hipStream_t st) { LAUNCH_G(kk_mtf, (size_t)p.m1 * p.m2, members, st, f, p, alpha, stride); }
+hipError_t k_noise_gang(float2* f, size_t stride, size_t n, float dose, uint32_t seed, const GangPar& gp, hipStream_t st) { LAUNCH_G(kk_noise, n, gp.n, st, f, n, dose, seed, 0u, stride, gp); }
+hipError_t k_crop_gang(float* J, const float2* I, size_t stride, const KP& p, const GangPar& gp, hipStream_t st) { LAUNCH_G(kk_crop, (size_t)p.n1 * p.n2, gp.n, st, J, I, p, stride, gp); }
 hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre, float alpha, hipStream_t st)
 {
     LAUNCH(kk_intensity_axpy, n, st, I, psi, n, pre, alpha);
@@ -552,14 +591,14 @@ hipError_t k_fftshift(float2* out, const float2* in, int m1, int m2, hipStream_t
 hipError_t k_mask_filter(float2* psi, const KP& p, hipStream_t st) { LAUNCH(kk_mask_filter, (size_t)p.m1 * p.m2, st, psi, p); }
 hipError_t k_spatial_incoherence(float2* f, const KP& p, float dk, int dp, hipStream_t st)
 {
-    LAUNCH(kk_spatial, (size_t)p.m1 * p.m2, st, f, p, dk, dp);
+    LAUNCH(kk_spatial, (size_t)p.m1 * p.m2, st, f, p, dk, dp, (size_t)0, GangPar{});
 }
-hipError_t k_mtf(float2* f, const KP& p, float alpha, hipStream_t st) { LAUNCH(kk_mtf, (size_t)p.m1 * p.m2, st, f, p, alpha); }
+hipError_t k_mtf(float2* f, const KP& p, float alpha, hipStream_t st) { LAUNCH(kk_mtf, (size_t)p.m1 * p.m2, st, f, p, alpha, (size_t)0); }
 hipError_t k_noise(float2* f, size_t n, float dose, uint32_t seed, int k, hipStream_t st)
 {
-    LAUNCH(kk_noise, n, st, f, n, dose, seed, (uint32_t)k);
+    LAUNCH(kk_noise, n, st, f, n, dose, seed, (uint32_t)k, (size_t)0, GangPar{});
 }
-hipError_t k_crop(float* J, const float2* I, const KP& p, hipStream_t st) { LAUNCH(kk_crop, (size_t)p.n1 * p.n2, st, J, I, p); }
+hipError_t k_crop(float* J, const float2* I, const KP& p, hipStream_t st) { LAUNCH(kk_crop, (size_t)p.n1 * p.n2, st, J, I, p, (size_t)0, GangPar{}); }
 hipError_t k_normalize_to(float2* f, size_t n, float target, float* scratch, hipStream_t st)
 {
     hipError_t e;
