@@ -183,7 +183,7 @@ struct fdes_plan {
     float* gxyzFP = nullptr;              // [gang][3 nAt] jittered coordinates (member 0 = xyzFP_d)
     float2* gscr = nullptr;               // [gang][m12] scratch of the members' 2-D transforms outside the slice loop
     std::vector<void*> gang_owned;        // per-member binning arrays of members >= 1
-    size_t recs_stride = 0, rowstart_stride = 0;
+    size_t recs_stride = 0, rowstart_stride = 0, seg_stride = 0;
     float2* peer_stage = nullptr;   // landing buffer for another GPU's partial sum (fdes_plan_accumulate_from)
     bool peer_host_only = false;    // the peer copy was refused once: partial sums are staged through host memory (option "peer_copy" 0 forces it)
     std::vector<float2> peer_host;
@@ -1003,6 +1003,29 @@ int gang_flush(fdes_plan* pl)
         RC(rcw);
         float* const xyz0 = pl->xyzFP_d;
         const AtomBins bins0 = pl->bins;
+        if (pl->nAt > 0) {
+            // tilt, jitter and binning of all members in one launch each (geometry.hip, *_gang): what config_atoms does
+            // member by member, to the bit
+            int ks[16], js[16];
+            float t0[16], t1[16];
+            bool same_k = true;
+            for (int g = 0; g < n; g++) {
+                ks[g] = pl->gq[(size_t)g].k; js[g] = pl->gq[(size_t)g].j;
+                t0[g] = pl->p.tiltspec[2 * ks[g]]; t1[g] = pl->p.tiltspec[2 * ks[g] + 1];
+                same_k = same_k && ks[g] == ks[0];
+            }
+            const size_t n3f = 3 * (size_t)pl->nAt;
+            if (same_k) {
+                RC(ensure_tilt(pl, ks[0]));
+                if (pl->p.frPh > 0) HIPCHK(c, geom_jitter_gang(pl->gxyzFP, pl->xyzK_d, 0, pl->dwf_d, pl->nAt, n, owner_ctx(pl)->seed, ks, js, c->stream));
+                else for (int g = 0; g < n; g++) HIPCHK(c, hipMemcpyAsync(pl->gxyzFP + (size_t)g * n3f, pl->xyzK_d, sizeof(float) * n3f, hipMemcpyDeviceToDevice, c->stream));
+            } else {
+                HIPCHK(c, geom_tilt_gang(pl->gxyzFP, pl->xyzTO_d, pl->nAt, n, t0, t1, c->stream));
+                if (pl->p.frPh > 0) HIPCHK(c, geom_jitter_gang(pl->gxyzFP, pl->gxyzFP, n3f, pl->dwf_d, pl->nAt, n, owner_ctx(pl)->seed, ks, js, c->stream));
+            }
+            BinGeom bg{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
+            HIPCHK(c, geom_bin_atoms_gang(pl->gxyzFP, pl->spec_d, pl->occ_d, pl->nAt, n, bg, pl->bins, pl->seg_stride, pl->rowstart_stride, c->stream));
+        } else
         for (int g = 0; g < n; g++) {
             pl->xyzFP_d = pl->gxyzFP + (size_t)g * 3 * (size_t)pl->nAt;
             pl->bins = pl->gbins[(size_t)g];
@@ -1438,31 +1461,29 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     // binning buffers sized for the larger of the sub-sliced and the original slicing
     const int m3max = pl->p.m3 > pl->p0.m3 ? pl->p.m3 : pl->p0.m3;
     pl->bins_cap_keys = m3max * pl->nZ;
-    PLCHK(dmalloc(c, &pl->bins.keys, (size_t)nAt));
-    PLCHK(dmalloc(c, &pl->bins.keys_sorted, (size_t)nAt));
-    PLCHK(dmalloc(c, &pl->bins.vals, (size_t)nAt));
-    PLCHK(dmalloc(c, &pl->bins.order, (size_t)nAt));
-    PLCHK(dmalloc(c, &pl->bins.seg, (size_t)pl->bins_cap_keys + 2));
-    PLCHK(dmalloc(c, &pl->bins.recs, (size_t)nAt));
-    pl->recs_stride = (size_t)(nAt > 0 ? nAt : 1);
+    // (gang: every binning array holds the members back to back - one sort serves them all, geom_bin_atoms_gang - and
+    //  member g works on its own range through the view gbins[g] when it is binned alone)
+    const size_t nA = (size_t)(nAt > 0 ? nAt : 1);
+    pl->recs_stride = nA;
+    pl->seg_stride = (size_t)pl->bins_cap_keys + 2;
     pl->rowstart_stride = (size_t)m3max * pl->nZ * (size_t)(pl->p.m2 + 1);
-    PLCHK(dmalloc(c, &pl->bins.recs_sorted, pl->recs_stride * G)); // (gang: the members' sorted records and row tables back to back)
+    PLCHK(dmalloc(c, &pl->bins.keys, nA * G));
+    PLCHK(dmalloc(c, &pl->bins.keys_sorted, nA * G));
+    PLCHK(dmalloc(c, &pl->bins.vals, nA * G));
+    PLCHK(dmalloc(c, &pl->bins.order, nA * G));
+    PLCHK(dmalloc(c, &pl->bins.seg, pl->seg_stride * G));
+    PLCHK(dmalloc(c, &pl->bins.recs, nA * G));
+    PLCHK(dmalloc(c, &pl->bins.recs_sorted, nA * G));
     PLCHK(dmalloc(c, &pl->bins.rowstart, pl->rowstart_stride * G)); // first sorted position of every (slice, species, row)
-    pl->bins.tmp_bytes = geom_sort_temp_bytes(nAt);
+    pl->bins.tmp_bytes = geom_sort_temp_bytes((int)(nA * G));
     PLHIP(hipMalloc(&pl->bins.tmp, pl->bins.tmp_bytes > 0 ? pl->bins.tmp_bytes : 16));
     pl->gbins.assign(G, pl->bins);
     pl->gseg.assign(G, {});
-    for (size_t g = 1; g < G; g++) { // members >= 1: own key / order / segment arrays, shared sort scratch (one stream)
-        AtomBins& b = pl->gbins[g];
-        b.recs_sorted = pl->bins.recs_sorted + g * pl->recs_stride;
-        b.rowstart = pl->bins.rowstart + g * pl->rowstart_stride;
-        b.keys = b.keys_sorted = b.vals = b.order = nullptr; b.seg = nullptr; b.recs = nullptr;
-        PLCHK(dmalloc(c, &b.keys, (size_t)nAt)); pl->gang_owned.push_back(b.keys);
-        PLCHK(dmalloc(c, &b.keys_sorted, (size_t)nAt)); pl->gang_owned.push_back(b.keys_sorted);
-        PLCHK(dmalloc(c, &b.vals, (size_t)nAt)); pl->gang_owned.push_back(b.vals);
-        PLCHK(dmalloc(c, &b.order, (size_t)nAt)); pl->gang_owned.push_back(b.order);
-        PLCHK(dmalloc(c, &b.seg, (size_t)pl->bins_cap_keys + 2)); pl->gang_owned.push_back(b.seg);
-        PLCHK(dmalloc(c, &b.recs, (size_t)nAt)); pl->gang_owned.push_back(b.recs);
+    for (size_t g = 1; g < G; g++) {
+        AtomBins& v = pl->gbins[g];
+        v.keys += g * nA; v.keys_sorted += g * nA; v.vals += g * nA; v.order += g * nA; v.recs += g * nA; v.recs_sorted += g * nA;
+        v.seg += g * pl->seg_stride;
+        v.rowstart += g * pl->rowstart_stride;
     }
     {   // enough blocks for an average segment, capped; the kernel strides over the rest
         long avg = (long)nAt / (pl->p.m3 > 0 ? pl->p.m3 : 1) + 1;

@@ -32,6 +32,12 @@ hipError_t geom_jitter(float* out, const float* in, const float* dwf, int nAt, u
 size_t geom_sort_temp_bytes(int nAt);
 hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, const float* occ, int nAt, const BinGeom& g, AtomBins& b, bool with_rows,
                           hipStream_t st);
+// the same for the n <= 16 members of a gang in one launch each (member g: atoms [g nAt, (g + 1) nAt) of every array)
+hipError_t geom_tilt_gang(float* out, const float* in, int nAt, int n, const float* t0, const float* t1, hipStream_t st);
+hipError_t geom_jitter_gang(float* out, const float* in, size_t in_stride, const float* dwf, int nAt, int n, uint32_t seed, const int* k,
+                            const int* j, hipStream_t st);
+hipError_t geom_bin_atoms_gang(const float* xyz, const uint8_t* spec, const float* occ, int nAt, int n, const BinGeom& g, AtomBins& b,
+                               size_t seg_stride, size_t rs_stride, hipStream_t st);
 hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key, const BinGeom& g,
                         float imPot, int blocks, hipStream_t st);
 

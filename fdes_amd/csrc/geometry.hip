@@ -12,6 +12,8 @@
 // (O(nAt * nZ * m3) threads per configuration).  Here atoms are binned once per configuration:
 // key = slice * nZ + species, a stable radix sort (rocPRIM) makes every (slice, species) a
 // contiguous segment, and the per-slice deposit touches only its own atoms.
+#include <cfloat>
+#include <cmath>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -94,6 +96,93 @@ __global__ void k_row_starts(const uint32_t* __restrict__ sorted, int nAt, int n
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const uint32_t q = (uint32_t)(e / (size_t)(m2 + 1)), row = (uint32_t)(e % (size_t)(m2 + 1));
         rowstart[e] = lower_bound_u32(sorted, nAt, q * (uint32_t)m2 + row);
+    }
+}
+
+// ---- the same steps for the n members of a gang in one launch each (engine.hip).  Member g's atoms are
+// [g nAt, (g + 1) nAt) of every per-atom array; its keys are offset by g KS, KS = (nq + 1) m2 (one more than a member's
+// largest key), so ONE stable sort leaves every member's records in its own range, in the order its own sort gives.
+
+struct GangGeo { int n; float c1[16], s1[16], c0[16], s0[16]; uint32_t k[16], j[16]; };
+
+// tiltCoordinates per member (geom_srot about axis (0, 2) with (c1, s1), then (1, 2) with (c0, s0); an angle within
+// FLT_EPSILON of zero is skipped as there: flags in bit 0 / 1 of do_rot[g]) from the common coordinates `in`
+__global__ void k_tilt_gang(float* __restrict__ out, const float* __restrict__ in, int nAt, GangGeo gg, unsigned rot1_mask, unsigned rot0_mask)
+{
+    const int g = blockIdx.y;
+    float* __restrict__ o = out + (size_t)g * 3 * (size_t)nAt;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nAt; i += gridDim.x * blockDim.x) {
+        float x = in[3 * i + 0], y = in[3 * i + 1], z = in[3 * i + 2];
+        if ((rot1_mask >> g) & 1u) { // axes (0, 2)
+            const float c = gg.c1[g], s = gg.s1[g];
+            const float cx = c * x, sy = s * z, cy = c * z, sx = s * x;
+            x = cx + sy;
+            z = cy - sx;
+        }
+        if ((rot0_mask >> g) & 1u) { // axes (1, 2)
+            const float c = gg.c0[g], s = gg.s0[g];
+            const float cx = c * y, sy = s * z, cy = c * z, sx = s * y;
+            y = cx + sy;
+            z = cy - sx;
+        }
+        o[3 * i + 0] = x; o[3 * i + 1] = y; o[3 * i + 2] = z;
+    }
+}
+
+// atomJitter per member: out_g = in_g + displacement(seed, k_g, j_g); in_stride = 0: every member starts from `in`
+__global__ void k_jitter_gang(float* __restrict__ out, const float* __restrict__ in, size_t in_stride, const float* __restrict__ dwf, int n3,
+                              uint32_t seed, GangGeo gg)
+{
+    const int g = blockIdx.y;
+    float* __restrict__ o = out + (size_t)g * (size_t)n3;
+    const float* __restrict__ src = in + (size_t)g * in_stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += gridDim.x * blockDim.x) {
+        const float x = normal(seed, 0u, gg.k[g], gg.j[g], (uint32_t)i);
+        const float d = (x * 0.112539540f) * sqrtf(dwf[i / 3]); // 1/(pi sqrt 8)
+        o[i] = src[i] + d;
+    }
+}
+
+__global__ void k_atom_keys_gang(const float* __restrict__ xyz, const uint8_t* __restrict__ spec, const float* __restrict__ occ, int nAt,
+                                 BinGeom g, uint32_t KS, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, AtomRec* __restrict__ recs)
+{
+    const int m = blockIdx.y;
+    const size_t base = (size_t)m * (size_t)nAt;
+    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < nAt; a += gridDim.x * blockDim.x) {
+        const size_t i = base + (size_t)a;
+        const float x1 = xyz[i * 3 + 0] / g.d1 + ((float)g.m1) * 0.5f - 0.5f;
+        const float x2 = xyz[i * 3 + 1] / g.d2 + ((float)g.m2) * 0.5f - 0.5f;
+        const float z3 = roundf(xyz[i * 3 + 2] / g.d3 + ((float)g.m3) * 0.5f - 0.5f);
+        uint32_t key = (uint32_t)(g.m3 * g.nZ) * (uint32_t)g.m2;
+        const bool inside = (x1 > 1.f) && (x1 < (float)(g.m1 - 2)) && (x2 > 1.f) && (x2 < (float)(g.m2 - 2));
+        const int i1 = (int)roundf(x1), i2 = (int)roundf(x2);
+        if (inside && z3 >= 0.f && z3 < (float)g.m3) key = (uint32_t)((int)z3 * g.nZ + (int)spec[a]) * (uint32_t)g.m2 + (uint32_t)i2;
+        keys[i] = key + (uint32_t)m * KS;
+        vals[i] = (uint32_t)i;
+        AtomRec r;
+        r.i1 = i1; r.i2 = i2; r.r1 = x1 - (float)i1; r.r2 = x2 - (float)i2; r.occ = occ[a]; r.pad = 0;
+        recs[i] = r;
+    }
+}
+
+__global__ void k_seg_bounds_gang(const uint32_t* __restrict__ sorted, int nAt, int nq, int m2, uint32_t KS, int* __restrict__ seg, size_t seg_stride)
+{
+    const int m = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nq) return;
+    seg[(size_t)m * seg_stride + (size_t)q] = lower_bound_u32(sorted + (size_t)m * (size_t)nAt, nAt, (uint32_t)m * KS + (uint32_t)q * (uint32_t)m2);
+}
+
+__global__ void k_row_starts_gang(const uint32_t* __restrict__ sorted, int nAt, int nq, int m2, uint32_t KS, int* __restrict__ rowstart,
+                                  size_t rs_stride)
+{
+    const int m = blockIdx.y;
+    const uint32_t* __restrict__ srt = sorted + (size_t)m * (size_t)nAt;
+    int* __restrict__ rs = rowstart + (size_t)m * rs_stride;
+    const size_t n = (size_t)nq * (size_t)(m2 + 1);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t q = (uint32_t)(e / (size_t)(m2 + 1)), row = (uint32_t)(e % (size_t)(m2 + 1));
+        rs[e] = lower_bound_u32(srt, nAt, (uint32_t)m * KS + q * (uint32_t)m2 + row);
     }
 }
 
@@ -274,6 +363,62 @@ hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, const float* oc
         e = hipGetLastError();
     }
     return e;
+}
+
+hipError_t geom_tilt_gang(float* out, const float* in, int nAt, int n, const float* t0, const float* t1, hipStream_t st)
+{
+    if (nAt <= 0 || n <= 0) return hipSuccess;
+    GangGeo gg{};
+    gg.n = n;
+    unsigned m1 = 0, m0 = 0;
+    for (int g = 0; g < n; g++) { // cos / sin on the host, c = cos t, s = -sin t, as tilt_coordinates does
+        if (fabsf(t1[g]) > FLT_EPSILON) { m1 |= 1u << g; gg.c1[g] = cosf(t1[g]); gg.s1[g] = -sinf(t1[g]); }
+        if (fabsf(t0[g]) > FLT_EPSILON) { m0 |= 1u << g; gg.c0[g] = cosf(t0[g]); gg.s0[g] = -sinf(t0[g]); }
+    }
+    hipLaunchKernelGGL(k_tilt_gang, dim3(blocks_for(nAt, 256, 2048), n), dim3(256), 0, st, out, in, nAt, gg, m1, m0);
+    return hipGetLastError();
+}
+
+hipError_t geom_jitter_gang(float* out, const float* in, size_t in_stride, const float* dwf, int nAt, int n, uint32_t seed, const int* k,
+                            const int* j, hipStream_t st)
+{
+    if (nAt <= 0 || n <= 0) return hipSuccess;
+    GangGeo gg{};
+    gg.n = n;
+    for (int g = 0; g < n; g++) { gg.k[g] = (uint32_t)k[g]; gg.j[g] = (uint32_t)j[g]; }
+    hipLaunchKernelGGL(k_jitter_gang, dim3(blocks_for(3 * nAt, 256, 2048), n), dim3(256), 0, st, out, in, in_stride, dwf, 3 * nAt, seed, gg);
+    return hipGetLastError();
+}
+
+// Binning of the n members' atoms (coordinates back to back in xyz) with ONE sort: `b` is member 0's view of arrays that
+// hold n members back to back (nAt keys / values / records per member, seg_stride / rs_stride ints per member);
+// tmp must hold geom_sort_temp_bytes(n * nAt).  Leaves exactly what n calls of geom_bin_atoms(with_rows) leave.
+hipError_t geom_bin_atoms_gang(const float* xyz, const uint8_t* spec, const float* occ, int nAt, int n, const BinGeom& g, AtomBins& b,
+                               size_t seg_stride, size_t rs_stride, hipStream_t st)
+{
+    const int nq = g.m3 * g.nZ;
+    if (nAt <= 0 || n <= 0) return hipErrorInvalidValue;
+    const uint64_t KS = ((uint64_t)nq + 1) * (uint64_t)g.m2;
+    if (KS * (uint64_t)n >= (1ull << 32)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_atom_keys_gang, dim3(blocks_for(nAt, 256, 2048), n), dim3(256), 0, st, xyz, spec, occ, nAt, g, (uint32_t)KS, b.keys, b.vals,
+                       b.recs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    unsigned bits = 1;
+    while ((1ull << bits) <= KS * (uint64_t)n && bits < 32) bits++;
+    size_t tb = b.tmp_bytes;
+    e = rocprim::radix_sort_pairs(b.tmp, tb, b.keys, b.keys_sorted, b.vals, b.order, (size_t)nAt * (size_t)n, 0u, bits, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_seg_bounds_gang, dim3((nq + 1 + 255) / 256, n), dim3(256), 0, st, b.keys_sorted, nAt, nq, g.m2, (uint32_t)KS, b.seg, seg_stride);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const size_t tot = (size_t)nAt * (size_t)n;
+    hipLaunchKernelGGL(k_gather_recs, dim3(blocks_for((int)(tot > 0x7fffffff ? 0x7fffffff : tot), 256, 4096)), dim3(256), 0, st, b.recs_sorted, b.recs,
+                       b.order, (int)tot);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const size_t nrs = (size_t)nq * (size_t)(g.m2 + 1);
+    hipLaunchKernelGGL(k_row_starts_gang, dim3(blocks_for((int)(nrs > 0x7fffffff ? 0x7fffffff : nrs), 256, 4096), n), dim3(256), 0, st, b.keys_sorted,
+                       nAt, nq, g.m2, (uint32_t)KS, b.rowstart, rs_stride);
+    return hipGetLastError();
 }
 
 hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key, const BinGeom& g,
