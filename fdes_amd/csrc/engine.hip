@@ -1194,20 +1194,19 @@ int plan_gang(const fdes_ctx* c, const fdes_plan* pl, bool* across_k = nullptr)
     if (c->gang == 0 || c->gang == 1 || units < 2) return 1;
     if (c->opt_fft == 1 || !Fft2D::lds_supported(pl->p.m1, pl->p.m2)) return 1;
     if (c->split > 0 || c->batch > 1 || c->pass_threads == 65 || c->walk > 1) return 1;
-    // auto (tools/bench_c4.py, SrTiO3 tilt series with 16 configurations per tilt, slice-propagations/s without a gang on
-    // three lanes -> with it on two): 256^2 76 k -> 226 k with 8 members (4: 155 k, 16 on one lane: 191 k), 512^2 53 k -> 121 k
-    // with 8 (4: 97 k), 800^2 22 k -> 28 k with 4 (8: 27 k), 1024^2 38 k -> 45 k with 4 (2: 40 k, 8: 40 k); from 2048^2 on one
-    // configuration's rows fill the chip.  At least two gangs per measurement resp. series, so that two lanes have work.
-    // A second lane doubles the set-up (plan, tables, graph capture: about 13 ms at 320^2) and pays from a few 10^9
-    // pixel-slices on (tools/bench_series.py, whole boundary call: bin/dataFDES.cnf 155 ms ungrouped, 62 ms with 8 x 2
-    // lanes, 30 ms with 16 members on one lane; C4, 2 x 10^10: 45 k on two lanes against 42 k on one): small jobs get one
-    // lane and larger gangs.
+    // auto (tools/gang_tables.sh -> profiles/r03_gang_tables.txt: SrTiO3 tilt series, 16 configurations per tilt,
+    // slice-propagations/s; without gangs on three lanes -> members x lanes): 256^2 76 k -> 302 k (16 x 1), 359 k (16 x 2), 279 k
+    // (8 x 2); 512^2 53 k -> 134 k (16 x 1), 139 k (8 x 2 and 16 x 2); 800^2 22 k -> 27 k (16 x 1), 28 k (4 x 2); 1024^2 38 k -> 46 k
+    // (8 x 1), 47-48 k (4 x 2), 43 k (8 x 2); from 2048^2 on one configuration's rows fill the chip.  Two lanes need two gangs
+    // per measurement resp. series.  A second lane doubles the set-up (streams, plan, tables) and pays from about 2 x 10^9
+    // pixel-slices on (whole boundary call: bin/dataFDES.cnf 150 ms ungrouped, 54 ms with 8 x 2 lanes, 23 ms with 16 members
+    // on one lane; 512^2 x 256 tilts 100 ms against 96 ms): small jobs get one lane and larger gangs.
     int g = c->gang;
     if (g < 0) {
         const size_t m12 = (size_t)pl->p.m1 * (size_t)pl->p.m2;
         if (gang_one_lane(c, pl)) g = m12 <= ((size_t)1 << 18) ? 16 : (m12 <= ((size_t)1 << 20) ? 8 : 1);
         else {
-            g = m12 <= ((size_t)1 << 18) ? 8 : (m12 <= ((size_t)1 << 20) ? 4 : 1);
+            g = m12 <= ((size_t)1 << 16) ? 16 : (m12 <= ((size_t)1 << 18) ? 8 : (m12 <= ((size_t)1 << 20) ? 4 : 1));
             if (units >= 4 && g > units / 2) g = units / 2;
         }
     }
