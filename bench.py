@@ -382,6 +382,21 @@ def run_extras(device):
                  "lanes": pl.lanes(), "gang": pl.gang(), "finite": bool(np.isfinite(img).all())}
     pl.close()
     eng.close()
+    # the reference's own shipped example (bin/dataFDES.cnf, a data fixture under tests/golden: Au-309, 320^2 wave, 25 specimen
+    # tilts, 12 slices -> 132 sub-slices, dose noise) through the boundary call with host buffers: what the CLI runs
+    ex = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "dataFDES_bin.cnf")
+    if os.path.exists(ex):
+        hp, at = fdes_amd.read_cnf(ex)
+        q, _ = fdes_amd.sub_sliced(hp)
+        eng = fdes_amd.Engine(device)
+        eng.build_measurements(hp, at)
+        t0 = time.perf_counter()
+        img = eng.build_measurements(hp, at)["image"]
+        dt = time.perf_counter() - t0
+        eng.close()
+        out["reference_example"] = {"workload": f"bin/dataFDES.cnf: Au-309, 320x320 wave, {hp.c.n3} tilts x {q.c.m3} sub-slices, fdes_build_measurements with host pointers",
+                                    "seconds": round(dt, 4), "value": round(hp.c.n3 * q.c.m3 / dt, 1), "unit": "slice-propagations/s",
+                                    "finite": bool(np.isfinite(img).all())}
     # the boundary call itself with HOST buffers (fdes_build_measurements: atoms in over PCIe, plan creation, tables,
     # 8 frozen-phonon configurations of the headline specimen, detector chain, image out over PCIe): the PCIe- and
     # setup-inclusive rate, never the headline
