@@ -908,13 +908,58 @@ int fft_gang(fdes_plan* pl, float2* data, int n, size_t stride, bool inverse)
     return FDES_OK;
 }
 
-// exit_wave_post of the n members of a gang (waves back to back in PSI) as six launches: imaging mode without an
-// exit-wave output; the other cases go member by member
+// bandwidthLimit of n grids m12 apart
+int bandwidth_limit_gang(fdes_plan* pl, float2* f, int n)
+{
+    RC(fft_gang(pl, f, n, pl->m12, false));
+    HIPCHK(pl->ctx, k_mask_scale_gang(f, pl->m12, n, pl->p.m1, pl->p.m2, 1.f / ((float)pl->m12), pl->ctx->stream));
+    return fft_gang(pl, f, n, pl->m12, true);
+}
+
+// incoming_wave of the n members (PSI, m12 apart).  Members of one k share their wave: built once, copied.  Members with a k
+// of their own (gangs across measurements): plane waves with a beam tilt take one launch per step for all members; a
+// CBED probe (own lens, own norm) is built member by member.
+int incoming_wave_gang(fdes_plan* pl, int n)
+{
+    fdes_ctx* c = pl->ctx;
+    const fdes_params& p = pl->p;
+    float2* const psi0 = pl->PSI;
+    bool same_k = true;
+    for (int g = 1; g < n; g++) same_k = same_k && pl->gq[(size_t)g].k == pl->gq[0].k;
+    if (n > 1 && !same_k && p.mode != 2 && pl->gscr) {
+        pl->wave_bl = true;
+        HIPCHK(c, k_fill(psi0, pl->m12 * (size_t)n, 1.f, 0.f, c->stream));
+        if (p.doBeamTilt) {
+            GangPar tb0, tb1;
+            tb0.n = tb1.n = n;
+            for (int g = 0; g < n; g++) { tb0.f[g] = p.tiltbeam[2 * pl->gq[(size_t)g].k]; tb1.f[g] = p.tiltbeam[2 * pl->gq[(size_t)g].k + 1]; }
+            HIPCHK(c, k_tilt_beam_gang(psi0, pl->m12, pl->kp, tb0, tb1, 1, c->stream));
+            HIPCHK(c, k_tukey_gang(psi0, pl->m12, n, pl->kp, c->stream));
+            RC(bandwidth_limit_gang(pl, psi0, n));
+        }
+        return FDES_OK;
+    }
+    int rcw = FDES_OK;
+    for (int g = 0; g < n && rcw == FDES_OK; g++) {
+        float2* const mine = psi0 + (size_t)g * pl->m12;
+        if (g > 0 && pl->gq[(size_t)g].k == pl->gq[(size_t)g - 1].k) {
+            if (hipMemcpyAsync(mine, mine - pl->m12, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rcw = FDES_EGPU;
+        } else {
+            pl->PSI = mine;
+            rcw = incoming_wave(pl, pl->gq[(size_t)g].k);
+            pl->PSI = psi0;
+        }
+    }
+    return rcw;
+}
+
+// exit_wave_post of the n members of a gang (waves back to back in PSI) in a handful of launches (no exit-wave output:
+// that case goes member by member)
 int exit_wave_post_gang(fdes_plan* pl, int n)
 {
     fdes_ctx* c = pl->ctx;
     const fdes_params& p = pl->p;
-    if (n <= 1 || p.mode != 0 || pl->want_ew || !pl->gscr) {
+    if (n <= 1 || pl->want_ew || !pl->gscr) {
         float2* const psi0 = pl->PSI;
         float2* const i0 = pl->I;
         int rce = FDES_OK;
@@ -934,10 +979,27 @@ int exit_wave_post_gang(fdes_plan* pl, int n)
         wt.f[g] = pl->gq[(size_t)g].w;
         wt.k[g] = pl->gq[(size_t)g].slot;
     }
+    if (p.mode == 0) {
+        RC(fft_gang(pl, pl->PSI, n, pl->m12, false));
+        HIPCHK(c, k_lens_gang(pl->PSI, pl->m12, pl->kp, dk, c->stream));
+        RC(fft_gang(pl, pl->PSI, n, pl->m12, true));
+        HIPCHK(c, k_intensity_gang(pl->I, pl->PSI, pl->m12, 1.f / ((float)pl->m12), wt, c->stream));
+        return FDES_OK;
+    }
+    // diffractionPattern (src/crystalMaker.cu:700-718), as exit_wave_post
+    if (p.doBeamTilt) {
+        GangPar tb0, tb1;
+        tb0.n = tb1.n = n;
+        for (int g = 0; g < n; g++) { tb0.f[g] = p.tiltbeam[2 * pl->gq[(size_t)g].k]; tb1.f[g] = p.tiltbeam[2 * pl->gq[(size_t)g].k + 1]; }
+        HIPCHK(c, k_tilt_beam_gang(pl->PSI, pl->m12, pl->kp, tb0, tb1, -1, c->stream));
+    }
+    if (p.mode == 1) {
+        HIPCHK(c, k_mask_filter_gang(pl->PSI, pl->m12, n, pl->kp, c->stream));
+        RC(bandwidth_limit_gang(pl, pl->PSI, n));
+    }
     RC(fft_gang(pl, pl->PSI, n, pl->m12, false));
-    HIPCHK(c, k_lens_gang(pl->PSI, pl->m12, pl->kp, dk, c->stream));
-    RC(fft_gang(pl, pl->PSI, n, pl->m12, true));
-    HIPCHK(c, k_intensity_gang(pl->I, pl->PSI, pl->m12, 1.f / ((float)pl->m12), wt, c->stream));
+    HIPCHK(c, k_fftshift_gang(pl->gscr, pl->PSI, pl->m12, n, p.m1, p.m2, c->stream)); // (the transforms are done with their scratch)
+    HIPCHK(c, k_intensity_gang(pl->I, pl->gscr, pl->m12, sqrtf(1.f / ((float)pl->m12)), wt, c->stream));
     return FDES_OK;
 }
 
@@ -988,19 +1050,7 @@ int gang_flush(fdes_plan* pl)
     const int n = (int)pl->gq.size();
     fdes_ctx* c = pl->ctx;
     if (n > 0) {
-        float2* const psi0 = pl->PSI;
-        int rcw = FDES_OK;
-        for (int g = 0; g < n && rcw == FDES_OK; g++) {
-            float2* const mine = psi0 + (size_t)g * pl->m12;
-            if (g > 0 && pl->gq[(size_t)g].k == pl->gq[(size_t)g - 1].k) {
-                if (hipMemcpyAsync(mine, mine - pl->m12, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rcw = FDES_EGPU;
-            } else {
-                pl->PSI = mine;
-                rcw = incoming_wave(pl, pl->gq[(size_t)g].k);
-                pl->PSI = psi0;
-            }
-        }
-        RC(rcw);
+        RC(incoming_wave_gang(pl, n));
         float* const xyz0 = pl->xyzFP_d;
         const AtomBins bins0 = pl->bins;
         if (pl->nAt > 0) {

@@ -49,6 +49,11 @@ hipError_t k_intensity_gang(float2* I, const float2* psi, size_t n, float pre, c
 hipError_t k_spatial_incoherence_gang(float2* f, size_t stride, const KP& p, int dp, const GangPar& gp, hipStream_t st); // f = defocus
 hipError_t k_mtf_gang(float2* f, size_t stride, int members, const KP& p, float alpha, hipStream_t st);
 hipError_t k_noise_gang(float2* f, size_t stride, size_t n, float dose, uint32_t seed, const GangPar& gp, hipStream_t st); // k = measurement
+hipError_t k_mask_scale_gang(float2* f, size_t stride, int members, int m1, int m2, float alpha, hipStream_t st);
+hipError_t k_tilt_beam_gang(float2* psi, size_t stride, const KP& p, const GangPar& tb0, const GangPar& tb1, int flag, hipStream_t st); // f = tilt
+hipError_t k_tukey_gang(float2* psi, size_t stride, int members, const KP& p, hipStream_t st);
+hipError_t k_fftshift_gang(float2* out, const float2* in, size_t stride, int members, int m1, int m2, hipStream_t st);
+hipError_t k_mask_filter_gang(float2* psi, size_t stride, int members, const KP& p, hipStream_t st);
 hipError_t k_crop_gang(float* J, const float2* I, size_t stride, const KP& p, const GangPar& gp, hipStream_t st);   // k = image of the stack
 hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre_scale, float alpha, hipStream_t st);
 hipError_t k_tilt_beam(float2* psi, const KP& p, float tb0, float tb1, int flag, hipStream_t st);

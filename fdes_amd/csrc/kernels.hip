@@ -176,8 +176,9 @@ __device__ __forceinline__ bool outside_band(int i1, int i2, float mindim)
 {
     return ((float)(i1 * i1 + i2 * i2) * 9.f / (mindim * mindim)) > 1.f;
 }
-__global__ void kk_mask_scale(float2* __restrict__ f, int m1, int m2, float alpha)
+__global__ void kk_mask_scale(float2* __restrict__ f, int m1, int m2, float alpha, size_t gstride)
 {
+    f += (size_t)blockIdx.y * gstride;
     const size_t n = (size_t)m1 * m2;
     const float mindim = (float)(m1 < m2 ? m1 : m2);
     GS_LOOP(i, n)
@@ -339,8 +340,10 @@ __global__ void kk_intensity_gang(float2* __restrict__ I, const float2* __restri
 }
 
 // ---- tiltBeam_d (src/multisliceSimulation.cu:89-120) -------------------------------------------
-__global__ void kk_tilt_beam(float2* __restrict__ psi, KP p, float tb0, float tb1, int flag)
+__global__ void kk_tilt_beam(float2* __restrict__ psi, KP p, float tb0, float tb1, int flag, size_t gstride, GangPar gp, GangPar gp1)
 {
+    psi += (size_t)blockIdx.y * gstride;
+    if (gp.n) { tb0 = gp.f[blockIdx.y]; tb1 = gp1.f[blockIdx.y]; }
     const size_t n = (size_t)p.m1 * p.m2;
     GS_LOOP(i, n)
     {
@@ -366,8 +369,9 @@ __device__ __forceinline__ float tukey1(int i, int dim, int dn)
     else if (x > 1.f - 0.5f * alpha) w = 0.5f * (1.f + cosf(PI_F * (2.f * x / alpha + 1.f - 2.f / alpha)));
     return w;
 }
-__global__ void kk_tukey(float2* __restrict__ psi, KP p)
+__global__ void kk_tukey(float2* __restrict__ psi, KP p, size_t gstride)
 {
+    psi += (size_t)blockIdx.y * gstride;
     const size_t n = (size_t)p.m1 * p.m2;
     GS_LOOP(i, n)
     {
@@ -381,8 +385,10 @@ __global__ void kk_tukey(float2* __restrict__ psi, KP p)
 }
 
 // ---- cufftShift2D_h (src/complexMath.cu:510-557): 4 strip kernels x 64 strips -> one out-of-place pass
-__global__ void kk_fftshift(float2* __restrict__ out, const float2* __restrict__ in, int m1, int m2)
+__global__ void kk_fftshift(float2* __restrict__ out, const float2* __restrict__ in, int m1, int m2, size_t gstride)
 {
+    out += (size_t)blockIdx.y * gstride;
+    in += (size_t)blockIdx.y * gstride;
     const size_t n = (size_t)m1 * m2;
     GS_LOOP(i, n)
     {
@@ -394,8 +400,9 @@ __global__ void kk_fftshift(float2* __restrict__ out, const float2* __restrict__
 }
 
 // ---- areaMask + areaWeighting (src/multisliceSimulation.cu:468-510, src/crystalMaker.cu:187-224)
-__global__ void kk_mask_filter(float2* __restrict__ psi, KP p)
+__global__ void kk_mask_filter(float2* __restrict__ psi, KP p, size_t gstride)
 {
+    psi += (size_t)blockIdx.y * gstride;
     const size_t n = (size_t)p.m1 * p.m2;
     GS_LOOP(i, n)
     {
@@ -554,7 +561,7 @@ hipError_t k_filter_accum_tab(float2* Vh, float2* Dh, const float* G, size_t n, 
 hipError_t k_pick_potential(float2* V, const float2* W, size_t n, int comp, float imPot, hipStream_t st) { LAUNCH(kk_pick_potential, n, st, V, W, n, comp, imPot); }
 hipError_t k_mask_scale(float2* f, int m1, int m2, float alpha, hipStream_t st)
 {
-    LAUNCH(kk_mask_scale, (size_t)m1 * m2, st, f, m1, m2, alpha);
+    LAUNCH(kk_mask_scale, (size_t)m1 * m2, st, f, m1, m2, alpha, (size_t)0);
 }
 hipError_t k_mul(float2* dst, const float2* f0, const float2* f1, size_t n, hipStream_t st) { LAUNCH(kk_mul, n, st, dst, f0, f1, n); }
 hipError_t k_build_propagator(float2* P, const KP& p, int transposed, hipStream_t st) { LAUNCH(kk_propagator, (size_t)p.m1 * p.m2, st, P, p, transposed); }
@@ -574,6 +581,11 @@ hipError_t k_intensity_gang(float2* I, const float2* psi, size_t n, float pre, c
 hipError_t k_spatial_incoherence_gang(float2* f, size_t stride, const KP& p, int dp, const GangPar& gp, hipStream_t st) { LAUNCH_G(kk_spatial, (size_t)p.m1 * p.m2, gp.n, st, f, p, 0.f, dp, stride, gp); }
 hipError_t k_mtf_gang(float2* f, size_t stride, int members, const KP& p, float alpha, hipStream_t st) { LAUNCH_G(kk_mtf, (size_t)p.m1 * p.m2, members, st, f, p, alpha, stride); }
 hipError_t k_noise_gang(float2* f, size_t stride, size_t n, float dose, uint32_t seed, const GangPar& gp, hipStream_t st) { LAUNCH_G(kk_noise, n, gp.n, st, f, n, dose, seed, 0u, stride, gp); }
+hipError_t k_mask_scale_gang(float2* f, size_t stride, int members, int m1, int m2, float alpha, hipStream_t st) { LAUNCH_G(kk_mask_scale, (size_t)m1 * m2, members, st, f, m1, m2, alpha, stride); }
+hipError_t k_tilt_beam_gang(float2* psi, size_t stride, const KP& p, const GangPar& tb0, const GangPar& tb1, int flag, hipStream_t st) { LAUNCH_G(kk_tilt_beam, (size_t)p.m1 * p.m2, tb0.n, st, psi, p, 0.f, 0.f, flag, stride, tb0, tb1); }
+hipError_t k_tukey_gang(float2* psi, size_t stride, int members, const KP& p, hipStream_t st) { LAUNCH_G(kk_tukey, (size_t)p.m1 * p.m2, members, st, psi, p, stride); }
+hipError_t k_fftshift_gang(float2* out, const float2* in, size_t stride, int members, int m1, int m2, hipStream_t st) { LAUNCH_G(kk_fftshift, (size_t)m1 * m2, members, st, out, in, m1, m2, stride); }
+hipError_t k_mask_filter_gang(float2* psi, size_t stride, int members, const KP& p, hipStream_t st) { LAUNCH_G(kk_mask_filter, (size_t)p.m1 * p.m2, members, st, psi, p, stride); }
 hipError_t k_crop_gang(float* J, const float2* I, size_t stride, const KP& p, const GangPar& gp, hipStream_t st) { LAUNCH_G(kk_crop, (size_t)p.n1 * p.n2, gp.n, st, J, I, p, stride, gp); }
 hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre, float alpha, hipStream_t st)
 {
@@ -581,14 +593,14 @@ hipError_t k_intensity_axpy(float2* I, const float2* psi, size_t n, float pre, f
 }
 hipError_t k_tilt_beam(float2* psi, const KP& p, float tb0, float tb1, int flag, hipStream_t st)
 {
-    LAUNCH(kk_tilt_beam, (size_t)p.m1 * p.m2, st, psi, p, tb0, tb1, flag);
+    LAUNCH(kk_tilt_beam, (size_t)p.m1 * p.m2, st, psi, p, tb0, tb1, flag, (size_t)0, GangPar{}, GangPar{});
 }
-hipError_t k_tukey(float2* psi, const KP& p, hipStream_t st) { LAUNCH(kk_tukey, (size_t)p.m1 * p.m2, st, psi, p); }
+hipError_t k_tukey(float2* psi, const KP& p, hipStream_t st) { LAUNCH(kk_tukey, (size_t)p.m1 * p.m2, st, psi, p, (size_t)0); }
 hipError_t k_fftshift(float2* out, const float2* in, int m1, int m2, hipStream_t st)
 {
-    LAUNCH(kk_fftshift, (size_t)m1 * m2, st, out, in, m1, m2);
+    LAUNCH(kk_fftshift, (size_t)m1 * m2, st, out, in, m1, m2, (size_t)0);
 }
-hipError_t k_mask_filter(float2* psi, const KP& p, hipStream_t st) { LAUNCH(kk_mask_filter, (size_t)p.m1 * p.m2, st, psi, p); }
+hipError_t k_mask_filter(float2* psi, const KP& p, hipStream_t st) { LAUNCH(kk_mask_filter, (size_t)p.m1 * p.m2, st, psi, p, (size_t)0); }
 hipError_t k_spatial_incoherence(float2* f, const KP& p, float dk, int dp, hipStream_t st)
 {
     LAUNCH(kk_spatial, (size_t)p.m1 * p.m2, st, f, p, dk, dp, (size_t)0, GangPar{});
