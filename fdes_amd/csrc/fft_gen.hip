@@ -35,6 +35,42 @@ struct GenFac {
     unsigned magic[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// factors and stage tables of an n-point row; false if n has a prime factor above 5 or more than 8 stages
+__host__ __device__ constexpr bool factorize(int n, GenFac& f)
+{
+    f.n = n;
+    f.nf = 0;
+    int m = n;
+    // large radices first: fewer stages (each stage is one trip of the tile through LDS)
+    const int cand[6] = {10, 8, 5, 4, 3, 2};
+    for (int ci = 0; ci < 6; ci++)
+        while (m % cand[ci] == 0 && m > 1) {
+            if (f.nf == 8) return false;
+            f.radix[f.nf++] = cand[ci];
+            m /= cand[ci];
+        }
+    if (m != 1) return false;
+    int Ns = 1;
+    for (int q = 0; q < f.nf; q++) {
+        f.nbf[q] = n / f.radix[q];
+        f.ns[q] = Ns;
+        f.tws[q] = n / (Ns * f.radix[q]);
+        f.magic[q] = (unsigned)(((1ull << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
+        Ns *= f.radix[q];
+    }
+    return true;
+}
+__host__ __device__ constexpr int gen_rows(int n) { return n > 512 ? 4 : 8; }
+// the whole description of an n-point pass, as a compile-time constant for the specialised kernels (k_gpass<NC != 0>)
+__host__ __device__ constexpr GenFac make_fac(int n)
+{
+    GenFac f;
+    factorize(n, f);
+    f.rows = gen_rows(n);
+    f.lrows = f.rows == 4 ? 2 : 3;
+    return f;
+}
+
 // 512 threads = 8 waves per workgroup (two workgroups per CU at 1000 points: 2 waves per SIMD hide the LDS round trips
 // of the stages); a row belongs to 512 / rows consecutive threads
 constexpr int kGenThreads = 512;
@@ -158,10 +194,13 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
 }
 
 // row FFTs of the whole tile; on return `cur` points at the image that holds the result (natural order)
+// (CT: F is a compile-time constant - the stage loop is unrolled, every stage's radix, counts and index arithmetic fold)
+template <bool CT>
 __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restrict__ twl, const GenFac& F, const bool inverse)
 {
     const float s = inverse ? -1.f : 1.f;
     const int tpr = kGenThreads >> F.lrows, row = (int)threadIdx.x / tpr, jt = (int)threadIdx.x - row * tpr; // tpr is a power of two
+#pragma unroll (CT ? 8 : 1)
     for (int q = 0; q < F.nf; q++) {
         const int rx = F.radix[q];
         switch (rx) {
@@ -172,7 +211,15 @@ __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restri
         case 8: gen_stage<8>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         default: gen_stage<10>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         }
-        __syncthreads();
+        // a stage of a row touches that row only: with 64 threads per row (rows up to 512 points) a row belongs to ONE wave,
+        // whose LDS accesses complete in program order - between its stages no workgroup barrier is needed, only the wave's
+        // own fence (behind the last stage the callers read the tile across rows again: barrier)
+        if (tpr == 64 && q + 1 < F.nf) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
         cf* t_ = cur; cur = other; other = t_;
     }
 }
@@ -181,9 +228,15 @@ __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restri
 __device__ __forceinline__ bool gen_outside(int i1, int i2, float md) { return ((float)(i1 * i1 + i2 * i2) * 9.f / (md * md)) > 1.f; }
 
 // EPT: elements a thread owns (element e = tid + 512 i of the R x N tile, row-major)
-template <int EPT, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 2)) void k_gpass(PassArgs A, GenFac F) // EPT <= 8 (rows up to 1024 points): two workgroups per CU (the species loop of MID_GTABN needs more than 128 registers)
+// NC: 0 = any supported length, described by the run-time argument; otherwise THE length, the description a constant
+// (the reference's shipped grids 320, 800, 1000: the generic kernel spends ten times the vector instructions per point
+// of the power-of-two kernels on stage bookkeeping and index arithmetic)
+template <int NC, int EPT, int PRE, int MID, int POST, bool STORE_T>
+__global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 2)) void k_gpass(PassArgs A, GenFac Frt) // EPT <= 8 (rows up to 1024 points): two workgroups per CU (the species loop of MID_GTABN needs more than 128 registers)
 {
+    constexpr bool CT = NC != 0;
+    constexpr GenFac FC = make_fac(CT ? NC : 320);
+    const GenFac F = CT ? FC : Frt;
     extern __shared__ cf glds[];
     const int N = F.n, R = F.rows, tid = threadIdx.x;
     const int tile = R * N;
@@ -250,7 +303,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
             const size_t zo = (size_t)z * A.species_stride;
             load_tile(in0 + zo, cur, false);
             __syncthreads();
-            if constexpr (PRE != XF_NONE) gen_fft(cur, other, twl, F, PRE == XF_INV);
+            if constexpr (PRE != XF_NONE) gen_fft<CT>(cur, other, twl, F, PRE == XF_INV);
 #pragma unroll
             for (int i = 0; i < EPT; i++)
                 if (valid(i)) {
@@ -332,7 +385,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
                 }
             load_tile(in1, cur, (A.skip_dead_loads & 2) != 0);
             __syncthreads();
-            if constexpr (PRE != XF_NONE) gen_fft(cur, other, twl, F, PRE == XF_INV);
+            if constexpr (PRE != XF_NONE) gen_fft<CT>(cur, other, twl, F, PRE == XF_INV);
 #pragma unroll
             for (int i = 0; i < EPT; i++)
                 if (valid(i)) keep_b[i] = cur[er[i] * N + ec[i]];
@@ -342,7 +395,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
                 if (valid(i)) cur[er[i] * N + ec[i]] = areg[i];
         }
         __syncthreads();
-        if constexpr (PRE != XF_NONE) gen_fft(cur, other, twl, F, PRE == XF_INV);
+        if constexpr (PRE != XF_NONE) gen_fft<CT>(cur, other, twl, F, PRE == XF_INV);
         // ---- point-wise operation on this thread's elements
         const float md = (float)A.mindim;
 #pragma unroll
@@ -387,7 +440,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
             }
         }
     };
-    if constexpr (POST != XF_NONE) gen_fft(cur, other, twl, F, POST == XF_INV);
+    if constexpr (POST != XF_NONE) gen_fft<CT>(cur, other, twl, F, POST == XF_INV);
     store_tile(out0);
     if constexpr (MID == MID_EXPIV_PAIR) {
         __syncthreads();
@@ -402,7 +455,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
                 cur[er[i] * N + ec[i]] = cf{e * cs, e * sn};
             }
         __syncthreads();
-        if constexpr (POST != XF_NONE) gen_fft(cur, other, twl, F, POST == XF_INV);
+        if constexpr (POST != XF_NONE) gen_fft<CT>(cur, other, twl, F, POST == XF_INV);
         store_tile(reinterpret_cast<cf*>(A.out2) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_out2 : (size_t)0));
     }
 }
@@ -410,37 +463,10 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
 #undef float2
 #undef make_float2
 
-bool factorize(int n, GenFac& f)
-{
-    f.n = n;
-    f.nf = 0;
-    int m = n;
-    // large radices first: fewer stages (each stage is one trip of the tile through LDS)
-    const int cand[6] = {10, 8, 5, 4, 3, 2};
-    for (int ci = 0; ci < 6; ci++)
-        while (m % cand[ci] == 0 && m > 1) {
-            if (f.nf == 8) return false;
-            f.radix[f.nf++] = cand[ci];
-            m /= cand[ci];
-        }
-    if (m != 1) return false;
-    int Ns = 1;
-    for (int q = 0; q < f.nf; q++) {
-        f.nbf[q] = n / f.radix[q];
-        f.ns[q] = Ns;
-        f.tws[q] = n / (Ns * f.radix[q]);
-        f.magic[q] = (unsigned)(((1ull << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
-        Ns *= f.radix[q];
-    }
-    return true;
-}
-
-int gen_rows(int n) { return n > 512 ? 4 : 8; }
-
-template <int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaunch(const PassArgs& a, const GenFac& f, hipStream_t st)
+template <int NC, int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaunch(const PassArgs& a, const GenFac& f, hipStream_t st)
 {
     static std::atomic<unsigned long long> attr_set{0};
-    auto kern = k_gpass<EPT, PRE, MID, POST, ST>;
+    auto kern = k_gpass<NC, EPT, PRE, MID, POST, ST>;
     // two images of the tile + the twiddle table
     const size_t lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * 2 + (size_t)f.n) + 64;
     int dev = 0;
@@ -476,9 +502,9 @@ template <int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaunch(const
     return hipGetLastError();
 }
 
-template <int EPT> hipError_t gdispatch(int pre, int mid, int post, bool st_t, const PassArgs& a, const GenFac& f, hipStream_t st)
+template <int NC, int EPT> hipError_t gdispatch(int pre, int mid, int post, bool st_t, const PassArgs& a, const GenFac& f, hipStream_t st)
 {
-#define CASE(P_, M_, Q_, S_) if (pre == P_ && mid == M_ && post == Q_ && st_t == S_) return glaunch<EPT, P_, M_, Q_, S_>(a, f, st);
+#define CASE(P_, M_, Q_, S_) if (pre == P_ && mid == M_ && post == Q_ && st_t == S_) return glaunch<NC, EPT, P_, M_, Q_, S_>(a, f, st);
     CASE(XF_NONE, MID_NONE, XF_NONE, false)
     CASE(XF_NONE, MID_NONE, XF_NONE, true)
     CASE(XF_NONE, MID_SCALE, XF_NONE, true)
@@ -526,8 +552,16 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
     f.rows = gen_rows(n);
     f.lrows = f.rows == 4 ? 2 : 3;
     const int ept = (f.rows * n + kGenThreads - 1) / kGenThreads;
-    if (ept <= 8) return gdispatch<8>(pre, mid, post, st_t, a, f, st);
-    if (ept <= 16) return gdispatch<16>(pre, mid, post, st_t, a, f, st);
+#ifndef FDES_GEN_SPECIALISED
+#define FDES_GEN_SPECIALISED 1
+#endif
+    if (FDES_GEN_SPECIALISED) { // the grids the reference ships (bin/dataFDES.cnf, bin/test.qsc, Si_001_11k_cnf)
+        if (n == 320) return gdispatch<320, 8>(pre, mid, post, st_t, a, f, st);
+        if (n == 800) return gdispatch<800, 8>(pre, mid, post, st_t, a, f, st);
+        if (n == 1000) return gdispatch<1000, 8>(pre, mid, post, st_t, a, f, st);
+    }
+    if (ept <= 8) return gdispatch<0, 8>(pre, mid, post, st_t, a, f, st);
+    if (ept <= 16) return gdispatch<0, 16>(pre, mid, post, st_t, a, f, st);
     return hipErrorInvalidValue;
 }
 
