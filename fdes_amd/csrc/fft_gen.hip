@@ -270,20 +270,18 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
         const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
         for (int i = tid; i < N; i += kGenThreads) twl[i] = tw[i];
     }
-    // this thread's elements: (row, column) of e = tid + 512 i; N >= 256, so a step wraps at most twice
+    // this thread's elements: columns jt + tpr i of ONE row (the 512 / R threads of a row are consecutive: their loads of a
+    // row are contiguous, and row and column need no arithmetic per element); EPT >= N / tpr = R N / 512
     int er[EPT], ec[EPT];
     {
-        int r = tid / N, c = tid - r * N;
+        const int tpr = kGenThreads >> F.lrows, r = tid >> (9 - F.lrows), c = tid & (tpr - 1);
 #pragma unroll
         for (int i = 0; i < EPT; i++) {
             er[i] = r;
-            ec[i] = c;
-            c += kGenThreads;
-            if (c >= N) { c -= N; r++; }
-            if (c >= N) { c -= N; r++; }
+            ec[i] = c + i * tpr;
         }
     }
-    auto valid = [&](int i) { return er[i] < R; };
+    auto valid = [&](int i) { return ec[i] < N; };
     auto load_tile = [&](const cf* __restrict__ src, cf* __restrict__ dstl, const bool band) {
 #pragma unroll
         for (int i = 0; i < EPT; i++)
