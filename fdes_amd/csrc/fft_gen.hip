@@ -553,10 +553,16 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
 #ifndef FDES_GEN_SPECIALISED
 #define FDES_GEN_SPECIALISED 1
 #endif
-    if (FDES_GEN_SPECIALISED) { // the grids the reference ships (bin/dataFDES.cnf, bin/test.qsc, Si_001_11k_cnf)
+    if (FDES_GEN_SPECIALISED) { // the grids the reference ships (bin/dataFDES.cnf, bin/test.qsc, Si_001_11k_cnf) and a few round ones
         if (n == 320) return gdispatch<320, 8>(pre, mid, post, st_t, a, f, st);
         if (n == 800) return gdispatch<800, 8>(pre, mid, post, st_t, a, f, st);
         if (n == 1000) return gdispatch<1000, 8>(pre, mid, post, st_t, a, f, st);
+        if (n == 400) return gdispatch<400, 8>(pre, mid, post, st_t, a, f, st);
+        if (n == 500) return gdispatch<500, 8>(pre, mid, post, st_t, a, f, st);
+        if (n == 640) return gdispatch<640, 8>(pre, mid, post, st_t, a, f, st);
+        if (n == 1280) return gdispatch<1280, 16>(pre, mid, post, st_t, a, f, st);
+        if (n == 1600) return gdispatch<1600, 16>(pre, mid, post, st_t, a, f, st);
+        if (n == 2000) return gdispatch<2000, 16>(pre, mid, post, st_t, a, f, st);
     }
     if (ept <= 8) return gdispatch<0, 8>(pre, mid, post, st_t, a, f, st);
     if (ept <= 16) return gdispatch<0, 16>(pre, mid, post, st_t, a, f, st);
