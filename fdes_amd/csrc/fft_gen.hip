@@ -78,7 +78,10 @@ constexpr int kGenThreads = 512;
 // s = +1 forward, -1 inverse: multiply by -i (forward) / +i (inverse)
 __device__ __forceinline__ cf mi_s(cf a, float s) { return cf{a.y * s, -a.x * s}; }
 // a * (c - i s_ sgn): the constant root of unity exp(-i phi) (forward) / exp(+i phi) (inverse), c = cos phi, sn = sin phi
-__device__ __forceinline__ cf rot_s(cf a, float c, float sn, float s) { return cf{a.x * c + a.y * (sn * s), a.y * c - a.x * (sn * s)}; }
+// (s is a constant at every call site - the transform direction is a template argument of the kernels - so the select folds;
+//  the products are the packed forms of fft_dev.inc: one packed multiply + one packed FMA instead of four scalar operations)
+__device__ __forceinline__ cf wmul_s(cf a, cf w, float s) { return s > 0.f ? cmul_rt(a, w) : cmulc_rt(a, w); } // a w (forward) / a conj(w) (inverse)
+__device__ __forceinline__ cf rot_s(cf a, float c, float sn, float s) { return wmul_s(a, cf{c, -sn}, s); }
 
 __device__ __forceinline__ void dft2(cf (&x)[10])
 {
@@ -171,15 +174,9 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
 #pragma unroll
         for (int i = 0; i < RX; i++) x[i] = srow[j + i * nb];
         if (Ns > 1) {
-            int ti = 0; // (i k tws) mod N, built incrementally
-            const int dk = k * tws;
+            const int dk = k * tws; // i k tws < RX Ns N / (Ns RX) = N: the table index needs no reduction
 #pragma unroll
-            for (int i = 1; i < RX; i++) {
-                ti += dk;
-                ti -= (ti >= N) ? N : 0;
-                const cf w = twl[ti];
-                x[i] = cf{x[i].x * w.x + x[i].y * (w.y * -s), x[i].y * w.x + x[i].x * (w.y * s)}; // * w (forward) or conj(w) (inverse)
-            }
+            for (int i = 1; i < RX; i++) x[i] = wmul_s(x[i], twl[i * dk], s); // * w (forward) or conj(w) (inverse)
         }
         if constexpr (RX == 2) dft2(x);
         if constexpr (RX == 3) dft3(x, s);

@@ -12,5 +12,5 @@ for r in rows:
     agg[r['Kernel_Name'][-60:]][r['Counter_Name']] += float(r['Counter_Value'])
 for k, v in agg.items():
     if 'pass' not in k: continue
-    print(k, {c: int(x) for c, x in v.items()}, 'conflict/active', round(v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1), 3))
+    print('lane-instr per point', round(v.get('SQ_INSTS_VALU',0)*64/($n*$n),1), k, {c: int(x) for c, x in v.items()}, 'conflict/active', round(v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1), 3))
 PY
