@@ -15,8 +15,8 @@
 //     A1_0 = astigmatism[A]*1e-9, A1_1 = angle[rad]*1e-9, mtf_d is never read (rwQsc.cu:943-1012).
 //   * atoms are shifted by -(max-min)/2 with min starting at 1 and max at 0 (rwQsc.cu:1041-1083).
 // Not carried over (returns FDES_EUNSUPPORTED with a message): `tds: yes` (QSTEM's Einstein
-// displacements at read time — FDES has its own frozen phonons), `Cube:` boxed mode, and unit
-// cells with partial or shared site occupancy (QSTEM removes atoms with ran1()).
+// displacements at read time — FDES has its own frozen phonons) and `Cube:` boxed mode.  Unit cells
+// with partial or shared site occupancy draw their vacancies with ran1() from its fixed seed, as QSTEM does.
 // `.cssr` and `.dat` cells are read the way the vendored readUnitCell reads them; the reference's
 // own readQsc ends the program for any cell file whose name holds no ".cfg" (rwQsc.cu:976-983).
 #include <algorithm>
@@ -348,6 +348,34 @@ int read_dat_atoms(const char* file, int ncoord, std::vector<QAtom>& atoms)
     return FDES_OK;
 }
 
+// ran1, fileio_fftw3.cpp:2559-2599: Park-Miller minimal standard generator with Bays-Durham shuffle, seeded with -1 (the
+// static idum of replicateUnitCell, :1196); uniform deviates in (0, 1)
+struct Ran1 {
+    static constexpr long IA = 16807, IM = 2147483647, IQ = 127773, IR = 2836, NTAB = 32, NDIV = 1 + (IM - 1) / NTAB;
+    long idum = -1, iy = 0, iv[NTAB] = {};
+    double next()
+    {
+        if (idum <= 0 || !iy) {
+            idum = (-idum < 1) ? 1 : -idum;
+            for (long j = NTAB + 7; j >= 0; j--) {
+                const long k = idum / IQ;
+                idum = IA * (idum - k * IQ) - IR * k;
+                if (idum < 0) idum += IM;
+                if (j < NTAB) iv[j] = idum;
+            }
+            iy = iv[0];
+        }
+        const long k = idum / IQ;
+        idum = IA * (idum - k * IQ) - IR * k;
+        if (idum < 0) idum += IM;
+        const long j = iy / NDIV;
+        iy = iv[j];
+        iv[j] = idum;
+        const double temp = (1.0 / IM) * iy;
+        return temp > 1.0 - 1.2e-7 ? 1.0 - 1.2e-7 : temp;
+    }
+};
+
 // rotateVect, matrixlib.cpp:599-634 (rotation about x, then y, then z)
 void rotate(double* u, double px, double py, double pz)
 {
@@ -399,23 +427,47 @@ int build_super_cell(const char* file, int ncx, int ncy, int ncz, float ctx, flo
         if (a.y != b.y) return a.y < b.y;
         return a.x < b.x;
     });
-    for (int i = nc - 1; i >= 0; i--) {
-        const bool shared = i > 0 && std::fabs(uc[i].x - uc[i - 1].x) < 1e-6 && std::fabs(uc[i].y - uc[i - 1].y) < 1e-6 &&
-                            std::fabs(uc[i].z - uc[i - 1].z) < 1e-6;
-        if (shared || uc[(size_t)i].occ < 1.0f)
-            return fail(FDES_EUNSUPPORTED, "unit cell with partial or shared site occupancy (QSTEM would draw vacancies with ran1)", file);
-    }
+    // replicateUnitCell with handleVacancies, fileio_fftw3.cpp:1188-1306: sites are visited from the last sorted atom
+    // backwards, atoms at one position (within 1e-6) form a site; a site with total occupancy below 1 or with several atoms
+    // draws ONE number per cell - cells from the last to the first - and keeps the atom whose occupancy interval holds it
+    // (none, if it falls beyond the sum), the others become vacancies (Znum 0, position and occupancy kept: they travel on
+    // to the engine as species 0, as they do in the reference).  ran1 starts from its seed of -1, as in a fresh process.
+    Ran1 rng;
     atoms.assign((size_t)nc * ncx * ncy * ncz, QAtom{});
-    for (int i = 0; i < nc; i++)
-        for (int icx = 0; icx < ncx; icx++)
-            for (int icy = 0; icy < ncy; icy++)
-                for (int icz = 0; icz < ncz; icz++) {
-                    QAtom& a = atoms[(size_t)(icz + icy * ncz + icx * ncy * ncz) * nc + i];
-                    a = uc[(size_t)i];
-                    a.x = uc[(size_t)i].x + (float)icx; // float + int + 0.0 (no thermal displacement)
-                    a.y = uc[(size_t)i].y + (float)icy;
-                    a.z = uc[(size_t)i].z + (float)icz;
+    for (int i = nc - 1; i >= 0;) {
+        int jequal = i - 1;
+        double totOcc = 1;
+        if (uc[(size_t)i].Znum > 0) {
+            totOcc = uc[(size_t)i].occ;
+            for (; jequal >= 0; jequal--) {
+                if (std::fabs(uc[(size_t)i].x - uc[(size_t)jequal].x) < 1e-6 && std::fabs(uc[(size_t)i].y - uc[(size_t)jequal].y) < 1e-6 &&
+                    std::fabs(uc[(size_t)i].z - uc[(size_t)jequal].z) < 1e-6)
+                    totOcc += uc[(size_t)jequal].occ;
+                else break;
+            }
+        }
+        for (int icx = ncx - 1; icx >= 0; icx--)
+            for (int icy = ncy - 1; icy >= 0; icy--)
+                for (int icz = ncz - 1; icz >= 0; icz--) {
+                    const size_t jCell = (size_t)(icz + icy * ncz + icx * ncy * ncz) * (size_t)nc;
+                    for (int i2 = i; i2 > jequal; i2--) atoms[jCell + (size_t)i2] = uc[(size_t)i2];
+                    if (totOcc < 1 || jequal < i - 1) {
+                        const double choice = totOcc < 1.0 ? rng.next() : totOcc * rng.next();
+                        double lastOcc = 0;
+                        for (int i2 = i; i2 > jequal; i2--) {
+                            if (choice < lastOcc || choice >= lastOcc + uc[(size_t)i2].occ) atoms[jCell + (size_t)i2].Znum = 0; // vacancy
+                            lastOcc += uc[(size_t)i2].occ;
+                        }
+                    }
+                    for (int i2 = i; i2 > jequal; i2--) {
+                        QAtom& a = atoms[jCell + (size_t)i2];
+                        a.x = uc[(size_t)i2].x + (float)icx; // float + int + 0.0 (no thermal displacement)
+                        a.y = uc[(size_t)i2].y + (float)icy;
+                        a.z = uc[(size_t)i2].z + (float)icz;
+                    }
                 }
+        i = jequal;
+    }
     const double(*Mm)[3] = cell.Mm;
     for (QAtom& a : atoms) { // fractional -> cartesian with the transposed cell matrix
         const double x = Mm[0][0] * a.x + Mm[1][0] * a.y + Mm[2][0] * a.z;

@@ -544,13 +544,76 @@ def test_read_qsc_needs_the_keys_the_reference_exits_on(tmp_path):
             fdes_amd.read_qsc(p)
 
 
-def test_cfg_reader_partial_occupancy_is_refused(tmp_path):
-    p = _write_qsc(tmp_path)
-    cfg = (tmp_path / "SrTiO3.cfg").read_text().replace("0.5 0.5 0.5  0.4390  1.0", "0.5 0.5 0.5  0.4390  0.5")
+def _ran1_sequence(n):
+    """ran1 of Numerical Recipes as the vendored QSTEM library has it (fileio_fftw3.cpp:2559-2599), seed -1."""
+    IA, IM, IQ, IR, NTAB = 16807, 2147483647, 127773, 2836, 32
+    NDIV = 1 + (IM - 1) // NTAB
+    idum, iv = 1, [0] * NTAB
+    for j in range(NTAB + 7, -1, -1):
+        k = idum // IQ
+        idum = IA * (idum - k * IQ) - IR * k
+        if idum < 0:
+            idum += IM
+        if j < NTAB:
+            iv[j] = idum
+    iy, out = iv[0], []
+    for _ in range(n):
+        k = idum // IQ
+        idum = IA * (idum - k * IQ) - IR * k
+        if idum < 0:
+            idum += IM
+        j = iy // NDIV
+        iy = iv[j]
+        iv[j] = idum
+        out.append(min(iy / IM, 1.0 - 1.2e-7))
+    return out
+
+
+def test_cfg_reader_partial_and_shared_occupancy_draws_vacancies_like_qstem(tmp_path):
+    """replicateUnitCell with handleVacancies (fileio_fftw3.cpp:1188-1306): the Ti site half occupied, and the first O
+    site shared by O (0.6) and N (0.3).  Sites are visited from the last sorted atom backwards, cells from the last to
+    the first, one ran1 deviate (seed -1) per cell and site; the atom whose occupancy interval holds the deviate stays,
+    the others become species 0 with their position and occupancy kept."""
+    p = _write_qsc(tmp_path, extra="slices: 4")
+    cfg = (tmp_path / "SrTiO3.cfg").read_text()
+    cfg = cfg.replace("0.5 0.5 0.5  0.4390  1.0", "0.5 0.5 0.5  0.4390  0.5")
+    cfg = cfg.replace("0 0.5 0.5  0.7323 1.0", "0 0.5 0.5  0.7323 0.6").replace("Number of particles = 5", "Number of particles = 6")
+    cfg += "14\nN\n0 0.5 0.5  0.5 0.3\n"
     (tmp_path / "SrTiO3.cfg").write_text(cfg)
-    with pytest.raises(fdes_amd.FdesError) as e:
-        fdes_amd.read_qsc(p)
-    assert e.value.code == -5
+    hp, at = fdes_amd.read_qsc(p)
+    ncx, ncy, ncz, nc = 2, 3, 2, 6
+    # the unit cell as it is sorted (z, y, x; file order reversed first, stable): index, Z, occupancy
+    cell = [(38, (0, 0, 0), 1.0), (22, (.5, .5, .5), 0.5), (8, (0, .5, .5), 0.6), (8, (.5, 0, .5), 1.0), (8, (.5, .5, 0), 1.0), (7, (0, .5, .5), 0.3)]
+    order = sorted(range(nc - 1, -1, -1), key=lambda i: (cell[i][1][2], cell[i][1][1], cell[i][1][0]))
+    uc = [cell[i] for i in order]
+    rnd = iter(_ran1_sequence(4 * ncx * ncy * ncz))
+    Z = np.zeros(nc * ncx * ncy * ncz, np.int32)
+    i = nc - 1
+    while i >= 0:
+        jeq, tot = i - 1, uc[i][2]
+        while jeq >= 0 and uc[jeq][1] == uc[i][1]:
+            tot += uc[jeq][2]
+            jeq -= 1
+        for icx in range(ncx - 1, -1, -1):
+            for icy in range(ncy - 1, -1, -1):
+                for icz in range(ncz - 1, -1, -1):
+                    jc = (icz + icy * ncz + icx * ncy * ncz) * nc
+                    for i2 in range(i, jeq, -1):
+                        Z[jc + i2] = uc[i2][0]
+                    if tot < 1 or jeq < i - 1:
+                        choice = next(rnd) if tot < 1.0 else tot * next(rnd)
+                        last = 0.0
+                        for i2 in range(i, jeq, -1):
+                            occ = float(np.float32(uc[i2][2]))
+                            if choice < last or choice >= last + occ:
+                                Z[jc + i2] = 0
+                            last += occ
+        i = jeq
+    assert at.n == Z.size and np.array_equal(at.Z, Z)
+    kept_ti = (at.Z == 22).sum()
+    assert 0 < kept_ti < ncx * ncy * ncz and (at.Z == 0).sum() > 0 and (at.Z == 7).sum() > 0
+    occ = at.occ.reshape(-1, nc)
+    assert np.allclose(occ, np.float32([u[2] for u in uc])[None, :])     # vacancies keep their occupancy
 
 
 def test_c_abi_from_plain_c(tmp_path):
