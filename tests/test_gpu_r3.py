@@ -1,6 +1,8 @@
 """GPU tests added in round 3: the incoming wave of a tilted CBED probe that leaves the 2/3 band (the first product of a
 configuration must see all of it, src/multisliceSimulation.cu:546, 583-590) and the exact launch path bench.py times
 (two lanes, hipGraph replay, frozen-phonon jitter) against the oracle at the headline size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -376,3 +378,26 @@ def test_gang_across_measurements_does_not_change_a_bit(oracle, kw):
                 assert np.array_equal(img, outs["off"]), (label, kw)
             else:
                 assert relerr(img, outs["off"]) < 2e-6, (label, kw, skip)
+
+
+def test_qsc_cell_with_vacancies_against_the_oracle(oracle, tmp_path):
+    """A .qsc whose unit cell has a half-occupied and a shared site: the front-end draws the vacancies with QSTEM's ran1;
+    they reach the engine as species 0 (the Kirkland fallback row, as in the reference), with their positions and
+    occupancies.  Image vs the float64 oracle on the same atom list."""
+    import shutil
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cfg = open(os.path.join(G, "qsc", "SrTiO3.cfg")).read()
+    cfg = cfg.replace("0.5 0.5 0.5  0.4390  1.0", "0.5 0.5 0.5  0.4390  0.5").replace("0 0.5 0.5  0.7323 1.0", "0 0.5 0.5  0.7323 0.6")
+    cfg = cfg.replace("Number of particles = 5", "Number of particles = 6") + "14\nN\n0 0.5 0.5  0.5 0.3\n"
+    (tmp_path / "SrTiO3.cfg").write_text(cfg)
+    (tmp_path / "v.qsc").write_text("mode: TEM\nfilename: SrTiO3.cfg\nNCELLX: 3\nNCELLY: 3\nNCELLZ: 4\nv0: 200\nslice-thickness: 1.9525\n"
+                                    "slices: 8\nnx: 128\nCs: 0.05\nalpha: 15\ndefocus: 13.7\ncal_mode: 0\nobjective_aperture: 20e-3\n"
+                                    "absorptive_potential_factor: 0.1\npixel_dose: 0\n")
+    hp, at = fdes_amd.read_qsc(tmp_path / "v.qsc")
+    assert at.n == 6 * 36 and 0 < (at.Z == 0).sum() < at.n and set(np.unique(at.Z)) == {0, 7, 8, 22, 38}
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0)
+    img = eng.build_measurements(hp, at)["image"]
+    eng.close()
+    ref = oracle.build_measurements(hp, at, prec="f64")["image"]
+    check(img, ref, None, 2e-5, "SrTiO3 .qsc with vacancies (species 0)")
