@@ -15,7 +15,8 @@
 //     A1_0 = astigmatism[A]*1e-9, A1_1 = angle[rad]*1e-9, mtf_d is never read (rwQsc.cu:943-1012).
 //   * atoms are shifted by -(max-min)/2 with min starting at 1 and max at 0 (rwQsc.cu:1041-1083).
 // Not carried over (returns FDES_EUNSUPPORTED with a message): `tds: yes` (QSTEM's Einstein
-// displacements at read time — FDES has its own frozen phonons) and `Cube:` boxed mode.  Unit cells
+// displacements at read time, seeded from the clock — FDES has its own frozen phonons).  `Cube:` boxes
+// the crystal the way tiltBoxed does.  Unit cells
 // with partial or shared site occupancy draw their vacancies with ran1() from its fixed seed, as QSTEM does.
 // `.cssr` and `.dat` cells are read the way the vendored readUnitCell reads them; the reference's
 // own readQsc ends the program for any cell file whose name holds no ".cfg" (rwQsc.cu:976-983).
@@ -399,8 +400,11 @@ void rotate(double* u, double px, double py, double pz)
 }
 
 // readUnitCell in NCELL mode, fileio_fftw3.cpp:1313-1657, with replicateUnitCell :1188-1306
+int boxed_super_cell(const std::vector<QAtom>& uc, const float* cube, float ctx, float cty, float ctz, float xOff, float yOff,
+                     std::vector<QAtom>& atoms, Cell& cell);
+
 int build_super_cell(const char* file, int ncx, int ncy, int ncz, float ctx, float cty, float ctz, float xOff, float yOff,
-                     std::vector<QAtom>& atoms, Cell& cell)
+                     const float* cube, std::vector<QAtom>& atoms, Cell& cell)
 {
     // format by file-name ending, fileio_fftw3.cpp:1340-1368 (.pdb and .xyz are refused there too)
     const size_t n = std::strlen(file);
@@ -427,6 +431,8 @@ int build_super_cell(const char* file, int ncx, int ncy, int ncz, float ctx, flo
         if (a.y != b.y) return a.y < b.y;
         return a.x < b.x;
     });
+    // boxed mode ("Cube:"): fileio_fftw3.cpp:1508-1513
+    if (cube[0] > 0 && cube[1] > 0 && cube[2] > 0) return boxed_super_cell(uc, cube, ctx, cty, ctz, xOff, yOff, atoms, cell);
     // replicateUnitCell with handleVacancies, fileio_fftw3.cpp:1188-1306: sites are visited from the last sorted atom
     // backwards, atoms at one position (within 1e-6) form a site; a site with total occupancy below 1 or with several atoms
     // draws ONE number per cell - cells from the last to the first - and keeps the atom whose occupancy interval holds it
@@ -522,6 +528,118 @@ int build_super_cell(const char* file, int ncx, int ncy, int ncz, float ctx, flo
     return FDES_OK;
 }
 
+// tiltBoxed, fileio_fftw3.cpp:1661-1925 (Einstein mode, no thermal displacements): the cell vectors are the COLUMNS of M,
+// rotated by the crystal tilt (rotateMatrix: M <- R M, matrixlib.cpp:637-675); the lattice indices needed to reach every
+// corner of the box [0, cube] - offset follow from inv(M) (inverse_3x3 with its identity fall-back for |det| < 0.0005,
+// matrixlib.cpp:225-257); every site of every such cell is kept when its cartesian position + offset lies in the box
+// (borders included), in the order site, ix, iy, iz.  A site with partial or shared occupancy draws one ran1 deviate per
+// cell; the atom whose occupancy interval holds it lends its species / Debye-Waller factor / occupancy, and when none does
+// the site's first atom is used (as there: jChoice starts as iatom and vacancies are only counted).
+int boxed_super_cell(const std::vector<QAtom>& uc, const float* cube, float ctx, float cty, float ctz, float xOff, float yOff,
+                     std::vector<QAtom>& atoms, Cell& cell)
+{
+    const int nc = (int)uc.size();
+    double M[9], Minv[9];
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) M[a * 3 + b] = cell.Mm[b][a];
+    if (ctx != 0 || cty != 0 || ctz != 0) { // the reference's cached rotation starts as the identity
+        const double px = ctx, py = cty, pz = ctz;
+        const double R[9] = {std::cos(pz) * std::cos(py), std::cos(pz) * std::sin(py) * std::sin(px) - std::sin(pz) * std::cos(px),
+                             std::cos(pz) * std::sin(py) * std::cos(px) + std::sin(pz) * std::sin(px),
+                             std::sin(pz) * std::cos(py), std::sin(pz) * std::sin(py) * std::sin(px) + std::cos(pz) * std::cos(px),
+                             std::sin(pz) * std::sin(py) * std::cos(px) - std::cos(pz) * std::sin(px),
+                             -std::sin(py), std::cos(py) * std::sin(px), std::cos(py) * std::cos(px)};
+        double T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                for (int k = 0; k < 3; k++) T[i * 3 + j] += R[i * 3 + k] * M[k * 3 + j];
+        std::memcpy(M, T, sizeof(M));
+    }
+    {
+        const double* a = M;
+        double det = a[0] * (a[4] * a[8] - a[7] * a[5]) - a[1] * (a[3] * a[8] - a[6] * a[5]) + a[2] * (a[3] * a[7] - a[6] * a[4]);
+        if (std::fabs(det) < 0.0005f) {
+            const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            std::memcpy(Minv, I, sizeof(Minv));
+        } else {
+            det = 1.0f / det;
+            Minv[0] = (a[4] * a[8] - a[5] * a[7]) * det;  Minv[1] = -(a[1] * a[8] - a[7] * a[2]) * det; Minv[2] = (a[1] * a[5] - a[4] * a[2]) * det;
+            Minv[3] = -(a[3] * a[8] - a[5] * a[6]) * det; Minv[4] = (a[0] * a[8] - a[6] * a[2]) * det;  Minv[5] = -(a[0] * a[5] - a[3] * a[2]) * det;
+            Minv[6] = (a[3] * a[7] - a[6] * a[4]) * det;  Minv[7] = -(a[0] * a[7] - a[6] * a[1]) * det; Minv[8] = (a[0] * a[4] - a[1] * a[3]) * det;
+        }
+    }
+    auto mul = [](const double* m, const double* v, double* o) { // matrixProduct(m, 3, 3, v, 3, 1, o): sums start from 0.0
+        for (int i = 0; i < 3; i++) {
+            o[i] = 0.0;
+            for (int k = 0; k < 3; k++) o[i] += m[i * 3 + k] * v[k];
+        }
+    };
+    const double dx = xOff, dy = yOff, dz = 0;
+    double a[3] = {0, 0, 0}, b[3];
+    mul(Minv, a, b);
+    int nxmin, nxmax, nymin, nymax, nzmin, nzmax;
+    nxmin = nxmax = (int)std::floor(b[0] - dx);
+    nymin = nymax = (int)std::floor(b[1] - dy);
+    nzmin = nzmax = (int)std::floor(b[2] - dz);
+    for (int ix = 0; ix <= 1; ix++)
+        for (int iy = 0; iy <= 1; iy++)
+            for (int iz = 0; iz <= 1; iz++) {
+                a[0] = ix * cube[0] - dx; a[1] = iy * cube[1] - dy; a[2] = iz * cube[2] - dz;
+                mul(Minv, a, b);
+                if (nxmin > (int)std::floor(b[0])) nxmin = (int)std::floor(b[0]);
+                if (nxmax < (int)std::ceil(b[0])) nxmax = (int)std::ceil(b[0]);
+                if (nymin > (int)std::floor(b[1])) nymin = (int)std::floor(b[1]);
+                if (nymax < (int)std::ceil(b[1])) nymax = (int)std::ceil(b[1]);
+                if (nzmin > (int)std::floor(b[2])) nzmin = (int)std::floor(b[2]);
+                if (nzmax < (int)std::ceil(b[2])) nzmax = (int)std::ceil(b[2]);
+            }
+    if ((double)(nxmax - nxmin + 1) * (nymax - nymin + 1) * (nzmax - nzmin + 1) * nc > 2.0e9) return fail(FDES_EINVAL, "'Cube:' box needs too many unit cells", nullptr);
+    Ran1 rng;
+    atoms.clear();
+    for (int iatom = 0; iatom < nc;) {
+        const QAtom& site = uc[(size_t)iatom];
+        int jequal = iatom + 1;
+        double totOcc = 1;
+        if (site.Znum > 0) {
+            totOcc = site.occ;
+            for (; jequal < nc; jequal++) {
+                if (std::fabs(site.x - uc[(size_t)jequal].x) < 1e-6 && std::fabs(site.y - uc[(size_t)jequal].y) < 1e-6 &&
+                    std::fabs(site.z - uc[(size_t)jequal].z) < 1e-6)
+                    totOcc += uc[(size_t)jequal].occ;
+                else break;
+            }
+        }
+        for (int ix = nxmin; ix <= nxmax; ix++)
+            for (int iy = nymin; iy <= nymax; iy++)
+                for (int iz = nzmin; iz <= nzmax; iz++) {
+                    const double aO[3] = {(double)((float)ix + site.x), (double)((float)iy + site.y), (double)((float)iz + site.z)}; // int + float
+                    int jChoice = iatom;
+                    if (totOcc < 1 || jequal > iatom + 1) {
+                        const double choice = totOcc < 1.0 ? rng.next() : totOcc * rng.next();
+                        double lastOcc = 0;
+                        for (int i2 = iatom; i2 < jequal; i2++) {
+                            if (!(choice < lastOcc || choice >= lastOcc + uc[(size_t)i2].occ)) jChoice = i2;
+                            lastOcc += uc[(size_t)i2].occ;
+                        }
+                    }
+                    mul(M, aO, b);
+                    const double x = b[0] + dx, y = b[1] + dy, z = b[2] + dz;
+                    if (x >= 0 && x <= cube[0] && y >= 0 && y <= cube[1] && z >= 0 && z <= cube[2]) {
+                        QAtom n = uc[(size_t)jChoice];
+                        n.x = (float)x;
+                        n.y = (float)y;
+                        n.z = (float)z;
+                        atoms.push_back(n);
+                    }
+                }
+        iatom = jequal;
+    }
+    cell.ax = cube[0];
+    cell.by = cube[1];
+    cell.c = cube[2];
+    return FDES_OK;
+}
+
 // wavelength(kev) in Angstroem, src/rwQsc.cu:1236-1247
 double qstem_wavelength(double kev)
 {
@@ -598,7 +716,7 @@ extern "C" int fdes_read_qsc(const char* file, fdes_params* p, fdes_atoms* atoms
     if (q.find("Crystal tilt Z:", r)) ctz = angle(r);
     float cube[3] = {0.f, 0.f, 0.f};
     if (q.find("Cube:", r)) std::sscanf(r.c_str(), "%g %g %g", &cube[0], &cube[1], &cube[2]);
-    if (cube[0] > 0 && cube[1] > 0 && cube[2] > 0) return fail(FDES_EUNSUPPORTED, "'Cube:' (boxed super cell) is not supported", file);
+    const bool boxed = cube[0] > 0 && cube[1] > 0 && cube[2] > 0;
     if (q.find("tds:", r) && yes(r)) return fail(FDES_EUNSUPPORTED, "'tds: yes' is not supported; use frozen_phonons", file);
 
     // atomPosFile: as given; without an extension ".cssr" is tried first, then ".cfg" (rwQsc.cu:181-210).  The
@@ -620,7 +738,7 @@ extern "C" int fdes_read_qsc(const char* file, fdes_params* p, fdes_atoms* atoms
 
     std::vector<QAtom> sc;
     Cell cell;
-    int rc = build_super_cell(cellPath.c_str(), ncx, ncy, ncz, ctx, cty, ctz, xOff, yOff, sc, cell);
+    int rc = build_super_cell(cellPath.c_str(), ncx, ncy, ncz, ctx, cty, ctz, xOff, yOff, cube, sc, cell);
     if (rc) return rc;
 
     int nx = 0, ny = 0;
@@ -635,17 +753,18 @@ extern "C" int fdes_read_qsc(const char* file, fdes_params* p, fdes_atoms* atoms
     std::sscanf(r.c_str(), "%g", &v0);
     int centerSlices = 0;
     if (q.find("center slices:", r)) centerSlices = yes(r);
-    // slice thickness / number of slices, src/rwQsc.cu:270-318 (cubez == 0 here)
+    // slice thickness / number of slices, src/rwQsc.cu:270-318 (boxed mode divides the box height instead of the cell's)
     float sliceTh = 0.f;
     int slices = 0;
     if (q.find("slice-thickness:", r)) {
         std::sscanf(r.c_str(), "%g", &sliceTh);
         if (q.find("slices:", r)) std::sscanf(r.c_str(), "%d", &slices);
-        else slices = (int)(cell.c / (cellDiv * sliceTh) + 0.99);
+        else slices = (int)((boxed ? cube[2] : cell.c) / (cellDiv * sliceTh) + 0.99);
         slices += centerSlices;
     } else if (q.find("slices:", r)) {
         std::sscanf(r.c_str(), "%d", &slices);
-        if (slices == 1 && cellDiv == 1) sliceTh = cell.c / cellDiv;
+        if (slices == 1 && cellDiv == 1) sliceTh = boxed ? (float)(centerSlices ? 2.0 * cube[2] / cellDiv : cube[2] / cellDiv) : cell.c / cellDiv;
+        else if (boxed) sliceTh = cube[2] / (cellDiv * slices - centerSlices); // (a zero divisor gives inf there as well)
         else if (slices > 0) sliceTh = cell.c / (cellDiv * slices);
     }
     if (slices <= 0) return fail(FDES_EINVAL, "number of slices = 0", file);

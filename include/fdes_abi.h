@@ -112,8 +112,8 @@ int fdes_read_emd(const char* file, fdes_params* p, fdes_atoms* atoms, int flags
 /* readQsc, src/rwQsc.cu:8-1101 (+ qstem-libs readparam / readUnitCell / replicateUnitCell): a QSTEM
  * `.qsc` file and the `.cfg` (or `.cssr` / `.dat`) unit cell it names -> parameters (n3 = 1) + the NCELL
  * super cell.  `p` from fdes_params_init; call fdes_params_consistent afterwards.  flags: FDES_CNF_SKIP_ATOMS.
- * Sites with partial or shared occupancy draw their vacancies (species 0) with QSTEM's ran1 from its fixed seed.
- * FDES_EUNSUPPORTED for non-TEM modes, `tds: yes`, `Cube:` and `.pdb`/`.xyz` cells. */
+ * Sites with partial or shared occupancy draw their vacancies (species 0) with QSTEM's ran1 from its fixed seed;
+ * `Cube:` boxes the (tilted) crystal.  FDES_EUNSUPPORTED for non-TEM modes, `tds: yes` and `.pdb`/`.xyz` cells. */
 int fdes_read_qsc(const char* file, fdes_params* p, fdes_atoms* atoms, int flags);
 /* Non-zero when libhdf5 (>= 1.10) could be loaded at run time (FDES_HDF5_LIB overrides the search). */
 int fdes_emd_available(void);

@@ -231,7 +231,30 @@ int main(int argc, char** argv)
             spit(T + "/cell.dat", mutate(dat));
             (void)read_with(fdes_read_qsc, T + "/d.qsc", 0);
         }
-        std::printf("fuzz: 400 .cnf, 200 .qsc, 50 .cfg, 50 .cssr, 50 .dat mutants parsed or refused\n");
+        // boxed mode and a cell with partial / shared occupancy: whole and mutated
+        {
+            std::string occ = cfg;
+            const std::string full = "0.5 0.5 0.5  0.4390  1.0";
+            const size_t at = occ.find(full);
+            if (at != std::string::npos) occ.replace(at, full.size(), "0.5 0.5 0.5  0.4390  0.5");
+            occ += "14\nN\n0.5 0.5 0.5  0.5 0.3\n";
+            const size_t np5 = occ.find("Number of particles = 5");
+            if (np5 != std::string::npos) occ.replace(np5, 23, "Number of particles = 6");
+            spit(T + "/SrTiO3.cfg", occ);
+            spit(T + "/b.qsc", base + "filename: SrTiO3.cfg\nCube: 13 11 9.5\nCrystal tilt Z: 0.2\nxOffset: 1.5\n");
+            int nb = 0;
+            EXPECT(read_with(fdes_read_qsc, T + "/b.qsc", 0, &nb) == FDES_OK && nb > 20);
+            EXPECT(read_with(fdes_read_qsc, T + "/ok.qsc", 0, &nb) == FDES_OK && nb == 6 * 1620);
+            for (int m = 0; m < 50; m++) {
+                spit(T + "/fuzzb.qsc", mutate(base + "filename: SrTiO3.cfg\nCube: 13 11 9.5\nCrystal tilt Z: 0.2\nxOffset: 1.5\n"));
+                (void)read_with(fdes_read_qsc, T + "/fuzzb.qsc", 0);
+                spit(T + "/SrTiO3.cfg", mutate(occ));
+                (void)read_with(fdes_read_qsc, T + "/b.qsc", 0);
+                spit(T + "/SrTiO3.cfg", occ);
+            }
+            spit(T + "/SrTiO3.cfg", cfg);
+        }
+        std::printf("fuzz: 400 .cnf, 200 .qsc, 50 .cfg, 50 .cssr, 50 .dat, 100 boxed / vacancy mutants parsed or refused\n");
     }
     // ---- atoms from a flat array (the legacy export's path)
     {

@@ -442,7 +442,7 @@ def test_read_qsc_slices_from_thickness_and_celldiv(tmp_path):
 
 
 @pytest.mark.parametrize("kw, code", [
-    (dict(mode="CBED"), -5), (dict(extra="tds: yes"), -5), (dict(extra="Cube: 10 10 10"), -5),
+    (dict(mode="CBED"), -5), (dict(extra="tds: yes"), -5),
     (dict(cfg="missing.cfg"), -2), (dict(cfg="missing.cssr"), -2), (dict(cfg="cell.pdb"), -5), (dict(cfg="cell.xyz"), -5)])
 def test_read_qsc_rejects_what_it_does_not_carry_over(tmp_path, kw, code):
     p = _write_qsc(tmp_path, **kw)
@@ -534,6 +534,57 @@ def test_read_qsc_cssr_oblique_cell_and_refusals(tmp_path):
     with pytest.raises(fdes_amd.FdesError) as e:
         fdes_amd.read_qsc(_write_qsc(tmp_path, cfg="SrTiO3.dat", extra="slices: 4"))
     assert e.value.code == -1
+
+
+@pytest.mark.parametrize("tilt, off", [((0.0, 0.0, 0.0), (0.0, 0.0)), ((0.1, -0.2, 0.25), (0.0, 0.0)), ((0.0, 0.3, 0.0), (1.5, -0.7))])
+def test_read_qsc_boxed_super_cell(tmp_path, tilt, off):
+    """`Cube:` (tiltBoxed, fileio_fftw3.cpp:1661-1925): the crystal, tilted about the origin, cut to the box [0, cube]
+    (borders included) after the x / y offset; lattice range from the box corners through inv(R M); atoms in the order
+    site (sorted z, y, x), ix, iy, iz; ax, by, c become the box; slices divide the box height.  Against an independent
+    numpy restatement."""
+    cube = (13.0, 11.0, 9.5)
+    extra = f"Cube: {cube[0]} {cube[1]} {cube[2]}\nslices: 5\nCrystal tilt X: {tilt[0]}\nCrystal tilt Y: {tilt[1]}\nCrystal tilt Z: {tilt[2]}\n" \
+            f"xOffset: {off[0]}\nyOffset: {off[1]}"
+    p = _write_qsc(tmp_path, extra=extra)
+    hp, at = fdes_amd.read_qsc(p)
+    f32 = np.float32
+    a = 3.905
+    px, py, pz = (float(f32(t)) for t in tilt)
+    R = np.eye(3)
+    if any(tilt):
+        R = np.array([[np.cos(pz) * np.cos(py), np.cos(pz) * np.sin(py) * np.sin(px) - np.sin(pz) * np.cos(px), np.cos(pz) * np.sin(py) * np.cos(px) + np.sin(pz) * np.sin(px)],
+                      [np.sin(pz) * np.cos(py), np.sin(pz) * np.sin(py) * np.sin(px) + np.cos(pz) * np.cos(px), np.sin(pz) * np.sin(py) * np.cos(px) - np.cos(pz) * np.sin(px)],
+                      [-np.sin(py), np.cos(py) * np.sin(px), np.cos(py) * np.cos(px)]])
+    M = R @ (a * np.eye(3))
+    Minv = np.linalg.inv(M)
+    d = np.array([float(f32(off[0])), float(f32(off[1])), 0.0])
+    cb = np.array([float(f32(c)) for c in cube])
+    lo = np.floor(Minv @ np.zeros(3) - d).astype(int)
+    hi = lo.copy()
+    for ix in (0, 1):
+        for iy in (0, 1):
+            for iz in (0, 1):
+                b = Minv @ (np.array([ix, iy, iz]) * cb - d)
+                lo = np.minimum(lo, np.floor(b).astype(int))
+                hi = np.maximum(hi, np.ceil(b).astype(int))
+    cell = [(38, (0, 0, 0), 0.6214), (22, (.5, .5, .5), 0.4390), (8, (0, .5, .5), 0.7323), (8, (.5, 0, .5), 0.7323), (8, (.5, .5, 0), 0.7323)]
+    cell.sort(key=lambda t: (t[1][2], t[1][1], t[1][0]))
+    Z, xyz = [], []
+    for z, fr, dw in cell:
+        for ix in range(lo[0], hi[0] + 1):
+            for iy in range(lo[1], hi[1] + 1):
+                for iz in range(lo[2], hi[2] + 1):
+                    pos = M @ (np.array([ix, iy, iz], float) + np.array(fr)) + d
+                    if np.all(pos >= 0) and np.all(pos <= cb):
+                        Z.append(z)
+                        xyz.append(pos)
+    Z = np.array(Z, np.int32)
+    xyz = (np.array(xyz).astype(f32).astype(np.float64) * 1e-10).astype(f32)
+    assert at.n == Z.size > 20 and np.array_equal(at.Z, Z)
+    shift = (np.maximum(xyz.max(0), f32(0)) - np.minimum(xyz.min(0), f32(1))) / f32(2)
+    assert np.allclose(at.xyz, xyz - shift, rtol=0, atol=3e-16)
+    c = hp.c
+    assert abs(c.d1 * c.n1 - cb[0] * 1e-10) < 1e-16 and c.m3 == 5 and abs(c.d3 - cb[2] / 5 * 1e-10) < 1e-17
 
 
 def test_read_qsc_needs_the_keys_the_reference_exits_on(tmp_path):
@@ -667,7 +718,7 @@ def _build_and_run(tmp_path, name, sources, flags, args=(), env=None):
     cmd = ["g++", "-std=c++17", "-O1", "-g", *flags, "-I", os.path.join(ROOT, "include"), "-o", exe,
            *[os.path.join(ROOT, s) for s in sources], "-ldl", "-lpthread"]
     subprocess.check_call(cmd)
-    return subprocess.run([exe, *args], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+    return subprocess.run([exe, *args], capture_output=True, text=True, errors="replace", timeout=600, env=dict(os.environ, **(env or {})))
 
 
 def test_multi_gpu_driver_under_thread_sanitizer(tmp_path):
