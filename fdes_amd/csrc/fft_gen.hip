@@ -197,8 +197,7 @@ __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restri
 {
     const float s = inverse ? -1.f : 1.f;
     const int tpr = kGenThreads >> F.lrows, row = (int)threadIdx.x / tpr, jt = (int)threadIdx.x - row * tpr; // tpr is a power of two
-#pragma unroll (CT ? 8 : 1)
-    for (int q = 0; q < F.nf; q++) {
+    auto stage = [&](const int q) {
         const int rx = F.radix[q];
         switch (rx) {
         case 2: gen_stage<2>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
@@ -218,6 +217,13 @@ __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restri
             __syncthreads();
         }
         cf* t_ = cur; cur = other; other = t_;
+    };
+    if constexpr (CT) {
+#pragma unroll
+        for (int q = 0; q < F.nf; q++) stage(q);
+    } else {
+#pragma unroll 1
+        for (int q = 0; q < F.nf; q++) stage(q);
     }
 }
 

@@ -14,8 +14,8 @@
 //   * dn = round(n/2) with integer division, m3 = slices, subSlTh = d3/10, C5_0 = C5[A]*1e-3,
 //     A1_0 = astigmatism[A]*1e-9, A1_1 = angle[rad]*1e-9, mtf_d is never read (rwQsc.cu:943-1012).
 //   * atoms are shifted by -(max-min)/2 with min starting at 1 and max at 0 (rwQsc.cu:1041-1083).
-// Not carried over (returns FDES_EUNSUPPORTED with a message): `tds: yes` (QSTEM's Einstein
-// displacements at read time, seeded from the clock — FDES has its own frozen phonons).  `Cube:` boxes
+// `tds: yes` applies QSTEM's Einstein displacements at read time (the reference seeds them from the clock; here a fixed
+// seed - FDES's own frozen phonons are the `frozen_phonons` of the engine and independent of this).  `Cube:` boxes
 // the crystal the way tiltBoxed does.  Unit cells
 // with partial or shared site occupancy draw their vacancies with ran1() from its fixed seed, as QSTEM does.
 // `.cssr` and `.dat` cells are read the way the vendored readUnitCell reads them; the reference's
@@ -377,6 +377,62 @@ struct Ran1 {
     }
 };
 
+// `tds: yes`: QSTEM's Einstein displacements at read time (phononDisplacement, fileio_fftw3.cpp:367-600, Einstein branch):
+// per site and cell u_i = sqrt(T / 300) sqrt(dw / (8 pi^2)) / sqrt(3) * gasdev(), cartesian, brought to reduced coordinates
+// with the inverse of the (untilted) cell matrix and added to the atom's reduced position.  The reference seeds gasdev from
+// the clock (:496), so there is no sequence to reproduce: the deviates here come from the same generator (gasdev over
+// ran1, :2607-2640) with a fixed seed, which makes a .qsc with `tds: yes` reproducible.
+struct Tds {
+    bool on = false;
+    double scale = 1.0;   // sqrt(tds_temp / 300), a float in the reference
+    double MmInv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    Ran1 rng;
+    bool have = false;
+    float gset = 0.f;
+    double gasdev()
+    {
+        if (have) { have = false; return gset; }
+        double v1, v2, rsq;
+        do {
+            v1 = 2.0 * rng.next() - 1.0;
+            v2 = 2.0 * rng.next() - 1.0;
+            rsq = v1 * v1 + v2 * v2;
+        } while (rsq >= 1.0 || rsq == 0.0);
+        const double fac = std::sqrt(-2.0 * std::log(rsq) / rsq);
+        gset = (float)(v1 * fac);
+        have = true;
+        return v2 * fac;
+    }
+    void init(const double (*Mm)[3], double temp)
+    {
+        on = true;
+        scale = (double)(float)std::sqrt(temp / 300.0);
+        rng.idum = -20130401; // any negative seed; fixed
+        double a[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) a[i * 3 + j] = Mm[j][i];
+        double det = a[0] * (a[4] * a[8] - a[7] * a[5]) - a[1] * (a[3] * a[8] - a[6] * a[5]) + a[2] * (a[3] * a[7] - a[6] * a[4]);
+        if (std::fabs(det) >= 0.0005f) { // inverse_3x3, matrixlib.cpp:225-257 (identity otherwise)
+            det = 1.0f / det;
+            MmInv[0] = (a[4] * a[8] - a[5] * a[7]) * det;  MmInv[1] = -(a[1] * a[8] - a[7] * a[2]) * det; MmInv[2] = (a[1] * a[5] - a[4] * a[2]) * det;
+            MmInv[3] = -(a[3] * a[8] - a[5] * a[6]) * det; MmInv[4] = (a[0] * a[8] - a[6] * a[2]) * det;  MmInv[5] = -(a[0] * a[5] - a[3] * a[2]) * det;
+            MmInv[6] = (a[3] * a[7] - a[6] * a[4]) * det;  MmInv[7] = -(a[0] * a[7] - a[6] * a[1]) * det; MmInv[8] = (a[0] * a[4] - a[1] * a[3]) * det;
+        }
+    }
+    // displacement of one site in reduced coordinates (zero when off)
+    void draw(double dw, double* uf)
+    {
+        uf[0] = uf[1] = uf[2] = 0.0;
+        if (!on) return;
+        const double pid = 3.14159265358979;
+        const double wobble = scale * std::sqrt(dw * (1.0 / (8 * pid * pid))), sq3 = 1.0 / std::sqrt(3.0);
+        double u[3];
+        for (int i = 0; i < 3; i++) u[i] = wobble * sq3 * gasdev();
+        for (int j = 0; j < 3; j++) // row vector times matrix, matrixProduct(&u, 1, 3, MmInv, 3, 3, &uf)
+            for (int k = 0; k < 3; k++) uf[j] += u[k] * MmInv[k * 3 + j];
+    }
+};
+
 // rotateVect, matrixlib.cpp:599-634 (rotation about x, then y, then z)
 void rotate(double* u, double px, double py, double pz)
 {
@@ -401,10 +457,10 @@ void rotate(double* u, double px, double py, double pz)
 
 // readUnitCell in NCELL mode, fileio_fftw3.cpp:1313-1657, with replicateUnitCell :1188-1306
 int boxed_super_cell(const std::vector<QAtom>& uc, const float* cube, float ctx, float cty, float ctz, float xOff, float yOff,
-                     std::vector<QAtom>& atoms, Cell& cell);
+                     Tds& tds, std::vector<QAtom>& atoms, Cell& cell);
 
 int build_super_cell(const char* file, int ncx, int ncy, int ncz, float ctx, float cty, float ctz, float xOff, float yOff,
-                     const float* cube, std::vector<QAtom>& atoms, Cell& cell)
+                     const float* cube, bool tds_on, float tds_temp, std::vector<QAtom>& atoms, Cell& cell)
 {
     // format by file-name ending, fileio_fftw3.cpp:1340-1368 (.pdb and .xyz are refused there too)
     const size_t n = std::strlen(file);
@@ -432,7 +488,9 @@ int build_super_cell(const char* file, int ncx, int ncy, int ncz, float ctx, flo
         return a.x < b.x;
     });
     // boxed mode ("Cube:"): fileio_fftw3.cpp:1508-1513
-    if (cube[0] > 0 && cube[1] > 0 && cube[2] > 0) return boxed_super_cell(uc, cube, ctx, cty, ctz, xOff, yOff, atoms, cell);
+    Tds tds;
+    if (tds_on) tds.init(cell.Mm, tds_temp);
+    if (cube[0] > 0 && cube[1] > 0 && cube[2] > 0) return boxed_super_cell(uc, cube, ctx, cty, ctz, xOff, yOff, tds, atoms, cell);
     // replicateUnitCell with handleVacancies, fileio_fftw3.cpp:1188-1306: sites are visited from the last sorted atom
     // backwards, atoms at one position (within 1e-6) form a site; a site with total occupancy below 1 or with several atoms
     // draws ONE number per cell - cells from the last to the first - and keeps the atom whose occupancy interval holds it
@@ -457,19 +515,23 @@ int build_super_cell(const char* file, int ncx, int ncy, int ncz, float ctx, flo
                 for (int icz = ncz - 1; icz >= 0; icz--) {
                     const size_t jCell = (size_t)(icz + icy * ncz + icx * ncy * ncz) * (size_t)nc;
                     for (int i2 = i; i2 > jequal; i2--) atoms[jCell + (size_t)i2] = uc[(size_t)i2];
+                    int jChoice = i;
                     if (totOcc < 1 || jequal < i - 1) {
                         const double choice = totOcc < 1.0 ? rng.next() : totOcc * rng.next();
                         double lastOcc = 0;
                         for (int i2 = i; i2 > jequal; i2--) {
                             if (choice < lastOcc || choice >= lastOcc + uc[(size_t)i2].occ) atoms[jCell + (size_t)i2].Znum = 0; // vacancy
+                            else jChoice = i2;
                             lastOcc += uc[(size_t)i2].occ;
                         }
                     }
+                    double u[3];
+                    tds.draw(uc[(size_t)jChoice].dw, u); // zero unless `tds: yes`; one displacement per site and cell
                     for (int i2 = i; i2 > jequal; i2--) {
                         QAtom& a = atoms[jCell + (size_t)i2];
-                        a.x = uc[(size_t)i2].x + (float)icx; // float + int + 0.0 (no thermal displacement)
-                        a.y = uc[(size_t)i2].y + (float)icy;
-                        a.z = uc[(size_t)i2].z + (float)icz;
+                        a.x = (float)((double)(uc[(size_t)i2].x + (float)icx) + u[0]); // float + int, + double
+                        a.y = (float)((double)(uc[(size_t)i2].y + (float)icy) + u[1]);
+                        a.z = (float)((double)(uc[(size_t)i2].z + (float)icz) + u[2]);
                     }
                 }
         i = jequal;
@@ -536,7 +598,7 @@ int build_super_cell(const char* file, int ncx, int ncy, int ncz, float ctx, flo
 // cell; the atom whose occupancy interval holds it lends its species / Debye-Waller factor / occupancy, and when none does
 // the site's first atom is used (as there: jChoice starts as iatom and vacancies are only counted).
 int boxed_super_cell(const std::vector<QAtom>& uc, const float* cube, float ctx, float cty, float ctz, float xOff, float yOff,
-                     std::vector<QAtom>& atoms, Cell& cell)
+                     Tds& tds, std::vector<QAtom>& atoms, Cell& cell)
 {
     const int nc = (int)uc.size();
     double M[9], Minv[9];
@@ -622,13 +684,17 @@ int boxed_super_cell(const std::vector<QAtom>& uc, const float* cube, float ctx,
                             lastOcc += uc[(size_t)i2].occ;
                         }
                     }
+                    double u[3];
+                    tds.draw(uc[(size_t)jChoice].dw, u); // (drawn for every cell, kept or not, as there)
                     mul(M, aO, b);
                     const double x = b[0] + dx, y = b[1] + dy, z = b[2] + dz;
-                    if (x >= 0 && x <= cube[0] && y >= 0 && y <= cube[1] && z >= 0 && z <= cube[2]) {
+                    if (x >= 0 && x <= cube[0] && y >= 0 && y <= cube[1] && z >= 0 && z <= cube[2]) { // the UNdisplaced position decides
+                        const double ad[3] = {aO[0] + u[0], aO[1] + u[1], aO[2] + u[2]};
+                        mul(M, ad, b);
                         QAtom n = uc[(size_t)jChoice];
-                        n.x = (float)x;
-                        n.y = (float)y;
-                        n.z = (float)z;
+                        n.x = (float)(b[0] + dx);
+                        n.y = (float)(b[1] + dy);
+                        n.z = (float)(b[2] + dz);
                         atoms.push_back(n);
                     }
                 }
@@ -717,7 +783,9 @@ extern "C" int fdes_read_qsc(const char* file, fdes_params* p, fdes_atoms* atoms
     float cube[3] = {0.f, 0.f, 0.f};
     if (q.find("Cube:", r)) std::sscanf(r.c_str(), "%g %g %g", &cube[0], &cube[1], &cube[2]);
     const bool boxed = cube[0] > 0 && cube[1] > 0 && cube[2] > 0;
-    if (q.find("tds:", r) && yes(r)) return fail(FDES_EUNSUPPORTED, "'tds: yes' is not supported; use frozen_phonons", file);
+    const bool tds_on = q.find("tds:", r) && yes(r);
+    float tds_temp = 300.0f;
+    if (q.find("temperature:", r)) std::sscanf(r.c_str(), "%g", &tds_temp);
 
     // atomPosFile: as given; without an extension ".cssr" is tried first, then ".cfg" (rwQsc.cu:181-210).  The
     // reference resolves it against the working directory; the .qsc's own directory is tried next.
@@ -738,7 +806,7 @@ extern "C" int fdes_read_qsc(const char* file, fdes_params* p, fdes_atoms* atoms
 
     std::vector<QAtom> sc;
     Cell cell;
-    int rc = build_super_cell(cellPath.c_str(), ncx, ncy, ncz, ctx, cty, ctz, xOff, yOff, cube, sc, cell);
+    int rc = build_super_cell(cellPath.c_str(), ncx, ncy, ncz, ctx, cty, ctz, xOff, yOff, cube, tds_on, tds_temp, sc, cell);
     if (rc) return rc;
 
     int nx = 0, ny = 0;

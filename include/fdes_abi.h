@@ -113,7 +113,8 @@ int fdes_read_emd(const char* file, fdes_params* p, fdes_atoms* atoms, int flags
  * `.qsc` file and the `.cfg` (or `.cssr` / `.dat`) unit cell it names -> parameters (n3 = 1) + the NCELL
  * super cell.  `p` from fdes_params_init; call fdes_params_consistent afterwards.  flags: FDES_CNF_SKIP_ATOMS.
  * Sites with partial or shared occupancy draw their vacancies (species 0) with QSTEM's ran1 from its fixed seed;
- * `Cube:` boxes the (tilted) crystal.  FDES_EUNSUPPORTED for non-TEM modes, `tds: yes` and `.pdb`/`.xyz` cells. */
+ * `Cube:` boxes the (tilted) crystal; `tds: yes` applies QSTEM's Einstein displacements at read time (fixed seed; the
+ * reference seeds them from the clock).  FDES_EUNSUPPORTED for non-TEM modes and `.pdb`/`.xyz` cells. */
 int fdes_read_qsc(const char* file, fdes_params* p, fdes_atoms* atoms, int flags);
 /* Non-zero when libhdf5 (>= 1.10) could be loaded at run time (FDES_HDF5_LIB overrides the search). */
 int fdes_emd_available(void);

@@ -241,7 +241,7 @@ int main(int argc, char** argv)
             const size_t np5 = occ.find("Number of particles = 5");
             if (np5 != std::string::npos) occ.replace(np5, 23, "Number of particles = 6");
             spit(T + "/SrTiO3.cfg", occ);
-            spit(T + "/b.qsc", base + "filename: SrTiO3.cfg\nCube: 13 11 9.5\nCrystal tilt Z: 0.2\nxOffset: 1.5\n");
+            spit(T + "/b.qsc", base + "filename: SrTiO3.cfg\nCube: 13 11 9.5\nCrystal tilt Z: 0.2\nxOffset: 1.5\ntds: yes\ntemperature: 600\n");
             int nb = 0;
             EXPECT(read_with(fdes_read_qsc, T + "/b.qsc", 0, &nb) == FDES_OK && nb > 20);
             EXPECT(read_with(fdes_read_qsc, T + "/ok.qsc", 0, &nb) == FDES_OK && nb == 6 * 1620);

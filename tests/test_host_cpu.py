@@ -442,7 +442,7 @@ def test_read_qsc_slices_from_thickness_and_celldiv(tmp_path):
 
 
 @pytest.mark.parametrize("kw, code", [
-    (dict(mode="CBED"), -5), (dict(extra="tds: yes"), -5),
+    (dict(mode="CBED"), -5),
     (dict(cfg="missing.cfg"), -2), (dict(cfg="missing.cssr"), -2), (dict(cfg="cell.pdb"), -5), (dict(cfg="cell.xyz"), -5)])
 def test_read_qsc_rejects_what_it_does_not_carry_over(tmp_path, kw, code):
     p = _write_qsc(tmp_path, **kw)
@@ -585,6 +585,35 @@ def test_read_qsc_boxed_super_cell(tmp_path, tilt, off):
     assert np.allclose(at.xyz, xyz - shift, rtol=0, atol=3e-16)
     c = hp.c
     assert abs(c.d1 * c.n1 - cb[0] * 1e-10) < 1e-16 and c.m3 == 5 and abs(c.d3 - cb[2] / 5 * 1e-10) < 1e-17
+
+
+def test_read_qsc_tds_applies_einstein_displacements(tmp_path):
+    """`tds: yes` (phononDisplacement, Einstein branch, fileio_fftw3.cpp:367-600): every site of every cell is displaced by
+    a Gaussian with <u_i^2> = (T / 300) dw / (8 pi^2) / 3 per cartesian component.  The reference seeds the generator from the
+    clock; here the seed is fixed: two reads agree to the bit, the displacements have the right size per species and scale
+    with the temperature, and atoms of one cell move independently."""
+    p0 = _write_qsc(tmp_path, extra="slices: 4")
+    hp0, a0 = fdes_amd.read_qsc(p0)
+    (tmp_path / "hot").mkdir()
+    outs = {}
+    for T in (300, 1200):
+        p = _write_qsc(tmp_path, extra=f"slices: 4\ntds: yes\ntemperature: {T}")
+        p = p.rename(tmp_path / f"t{T}.qsc")
+        hp, at = fdes_amd.read_qsc(p)
+        hp_b, at_b = fdes_amd.read_qsc(p)
+        assert np.array_equal(at.xyz, at_b.xyz) and np.array_equal(at.Z, a0.Z)
+        outs[T] = at.xyz.astype(np.float64)
+    # undo the centring shift of readQsc (it moves with the extreme atoms): compare displacements about their mean per axis
+    for T, xyz in outs.items():
+        d = xyz - a0.xyz.astype(np.float64)
+        d -= d.mean(0)
+        for Z, dw in ((38, 0.6214), (22, 0.4390), (8, 0.7323)):
+            sel = a0.Z == Z
+            want = np.sqrt(T / 300.0 * dw / (8 * np.pi ** 2) / 3.0) * 1e-10
+            got = d[sel].std()
+            assert abs(got / want - 1) < (0.35 if sel.sum() < 20 else 0.25), (T, Z, got, want)
+    d300 = outs[300] - a0.xyz
+    assert abs(np.corrcoef(d300[:-1, 0], d300[1:, 0])[0, 1]) < 0.4      # neighbours in the list move independently
 
 
 def test_read_qsc_needs_the_keys_the_reference_exits_on(tmp_path):
