@@ -90,6 +90,8 @@ def main():
     k_au = 30 if m >= 2048 else max(2, int(30 * m / 2048))
     hp, atoms = specimens.case_c3(k=k_au, n=m // 2, dn=m // 4, m3=args.slices, frPh=32)
     fdes_amd.consistent(hp)
+    probe_alone = {"ms": 0.0, "n": 0}
+
     def timed_run(skip_empty):
         """K timed steps on a fresh engine/plan; returns (seconds, plan, engine, loop_ms, loop_slices, fft_ms, fft_n, finite)."""
         eng = fdes_amd.Engine(local, fft=args.fft, probe_stride=0, lanes=args.lanes,
@@ -127,12 +129,18 @@ def main():
             dt = float(tmax.item())
         loop_ms, loop_slices = plan.slice_loop_ms()
         # roofline leg: one more configuration on lane 0 with the other lanes idle, every `probe_stride`-th launch of the
-        # dominant kernel (P5) bracketed by HIP events on the engine's stream.  (Inside the timed region two lanes share the
-        # chip: an event pair there spans the wait for the other lane's kernel as well as the execution, and would not
-        # agree with the profiler's kernel durations.)
+        # dominant kernel (P5) bracketed by the start / stop events of the dispatch itself (hipExtLaunchKernelGGL: kernel
+        # begin / end as a profiler sees them).  Before it the same with one configuration per lane, the lanes sharing the
+        # chip (`launch_us_lanes`): issued directly instead of replayed as graphs, a kernel's begin-to-end span then also
+        # holds the time its workgroups wait for the other lane's to retire (26 us against 21.6 us under rocprofv3 for the
+        # replayed loop and 22.5-23 us alone), so the lane-0-alone figure is the one `frac` is quoted on.
         plan.probe_ms()
-        eng.set_option("lanes_active", 1)
         eng.set_option("probe_stride", args.probe_stride)
+        for l in range(plan.lanes()):
+            plan.run_config(0, 3000 + rank + 100 * l, 0.0)
+        plan.sync()
+        alone_ms, alone_n = plan.probe_ms()          # (with every lane active)
+        eng.set_option("lanes_active", 1)
         plan.run_config(0, 2000 + rank, 0.0)
         plan.sync()
         fft_ms, fft_n = plan.probe_ms()
@@ -154,11 +162,13 @@ def main():
             plan.copy_intensity_real(buf.data_ptr(), 1)
         plan.end_measurement(0)
         img = plan.get_images()
+        probe_alone["ms"], probe_alone["n"] = alone_ms, alone_n
         return dt, plan, eng, loop_ms, loop_slices, fft_ms, fft_n, bool(np.isfinite(img).all()), img
 
     weight = 1.0 / 32.0
     # headline: EVERY slice runs the full potential / transmission / propagation sequence (what the reference does)
     dt, plan, eng, loop_ms, loop_slices, fft_ms, fft_n, finite, img0 = timed_run(args.skip_empty)
+    alone_ms, alone_n = probe_alone["ms"], probe_alone["n"]
     m3 = plan.m3
 
     total_slices = world * args.steps * m3
@@ -190,6 +200,7 @@ def main():
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_stale": stale,
                 "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": int(fft_n),
+                "launch_us_lanes": (round(alone_ms / alone_n * 1e3, 2) if fused and alone_n else None),
                 # the same kernel with its operands in HBM only (8 buffer sets round-robin on one stream, 1.2 GB at 2048^2:
                 # beyond the 256 MiB Infinity Cache, whose hits no rocprofv3 counter of this box exposes); `frac` above is
                 # measured inside the slice loop, where part of the traffic is served by that cache
@@ -197,7 +208,8 @@ def main():
                                                          "hbm_frac": round(alg_bytes / (cold * 1e-6) / 8e12, 4)}),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "timed": "HIP start/stop events of the dispatch itself (hipExtLaunchKernelGGL) on every %d-th launch during one "
-                         "configuration run on lane 0 right after the timed steps (other lanes idle)" % args.probe_stride}
+                         "configuration run on lane 0 right after the timed steps (other lanes idle); launch_us_lanes: the same "
+                         "with one configuration per lane sharing the chip, issued directly" % args.probe_stride}
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline:
         cpu = cpu_baseline(hp, atoms, m)
