@@ -90,7 +90,7 @@ def main():
     k_au = 30 if m >= 2048 else max(2, int(30 * m / 2048))
     hp, atoms = specimens.case_c3(k=k_au, n=m // 2, dn=m // 4, m3=args.slices, frPh=32)
     fdes_amd.consistent(hp)
-    probe_alone = {"ms": 0.0, "n": 0}
+    probe_lanes = {"ms": 0.0, "n": 0}
 
     def timed_run(skip_empty):
         """K timed steps on a fresh engine/plan; returns (seconds, plan, engine, loop_ms, loop_slices, fft_ms, fft_n, finite)."""
@@ -139,7 +139,7 @@ def main():
         for l in range(plan.lanes()):
             plan.run_config(0, 3000 + rank + 100 * l, 0.0)
         plan.sync()
-        alone_ms, alone_n = plan.probe_ms()          # (with every lane active)
+        lanes_ms, lanes_n = plan.probe_ms()          # (with every lane active)
         eng.set_option("lanes_active", 1)
         plan.run_config(0, 2000 + rank, 0.0)
         plan.sync()
@@ -162,13 +162,13 @@ def main():
             plan.copy_intensity_real(buf.data_ptr(), 1)
         plan.end_measurement(0)
         img = plan.get_images()
-        probe_alone["ms"], probe_alone["n"] = alone_ms, alone_n
+        probe_lanes["ms"], probe_lanes["n"] = lanes_ms, lanes_n
         return dt, plan, eng, loop_ms, loop_slices, fft_ms, fft_n, bool(np.isfinite(img).all()), img
 
     weight = 1.0 / 32.0
     # headline: EVERY slice runs the full potential / transmission / propagation sequence (what the reference does)
     dt, plan, eng, loop_ms, loop_slices, fft_ms, fft_n, finite, img0 = timed_run(args.skip_empty)
-    alone_ms, alone_n = probe_alone["ms"], probe_alone["n"]
+    lanes_ms, lanes_n = probe_lanes["ms"], probe_lanes["n"]
     m3 = plan.m3
 
     total_slices = world * args.steps * m3
@@ -200,7 +200,7 @@ def main():
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_stale": stale,
                 "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": int(fft_n),
-                "launch_us_lanes": (round(alone_ms / alone_n * 1e3, 2) if fused and alone_n else None),
+                "launch_us_lanes": (round(lanes_ms / lanes_n * 1e3, 2) if fused and lanes_n else None),
                 # the same kernel with its operands in HBM only (8 buffer sets round-robin on one stream, 1.2 GB at 2048^2:
                 # beyond the 256 MiB Infinity Cache, whose hits no rocprofv3 counter of this box exposes); `frac` above is
                 # measured inside the slice loop, where part of the traffic is served by that cache
