@@ -310,16 +310,18 @@ int ensure_tilt(fdes_plan* pl, int k)
 }
 
 // src/crystalMaker.cu:335-337 + the per-configuration (slice, species) binning
-int config_atoms(fdes_plan* pl, int k, int j, bool query = true)
+int config_atoms(fdes_plan* pl, int k, int j, bool query = true, float* xyz = nullptr, AtomBins* bins_p = nullptr) // xyz / bins_p: a gang member's coordinates and binning buffers
 {
+    float* const xyzFP = xyz ? xyz : pl->xyzFP_d;
+    AtomBins& bins = bins_p ? *bins_p : pl->bins;
     fdes_ctx* c = pl->ctx;
     RC(ensure_tilt(pl, k));
     if (pl->p.frPh > 0)
-        HIPCHK(c, geom_jitter(pl->xyzFP_d, pl->xyzK_d, pl->dwf_d, pl->nAt, owner_ctx(pl)->seed, k, j, c->stream));
+        HIPCHK(c, geom_jitter(xyzFP, pl->xyzK_d, pl->dwf_d, pl->nAt, owner_ctx(pl)->seed, k, j, c->stream));
     else
-        HIPCHK(c, hipMemcpyAsync(pl->xyzFP_d, pl->xyzK_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(xyzFP, pl->xyzK_d, sizeof(float) * 3 * (size_t)pl->nAt, hipMemcpyDeviceToDevice, c->stream));
     BinGeom g{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
-    HIPCHK(c, geom_bin_atoms(pl->xyzFP_d, pl->spec_d, pl->occ_d, pl->nAt, g, pl->bins, pl->fused || owner_ctx(pl)->deterministic, c->stream));
+    HIPCHK(c, geom_bin_atoms(xyzFP, pl->spec_d, pl->occ_d, pl->nAt, g, bins, pl->fused || owner_ctx(pl)->deterministic, c->stream));
     if (!query) return FDES_OK; // (a gang asks once for all its members, gang_flush)
     fdes_plan* tp = pl->top ? pl->top : pl;
     constexpr int kDenseAfter = 8, kDenseRecheck = 64;
@@ -329,7 +331,7 @@ int config_atoms(fdes_plan* pl, int k, int j, bool query = true)
     if (ask) {
         // which slices hold atoms decides the launch sequence: one small D2H per configuration
         pl->seg_h.resize((size_t)pl->p.m3 * pl->nZ + 1);
-        HIPCHK(c, hipMemcpyAsync(pl->seg_h.data(), pl->bins.seg, sizeof(int) * pl->seg_h.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(pl->seg_h.data(), bins.seg, sizeof(int) * pl->seg_h.size(), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         tp->empty_queries++;
         bool any_empty = false;
@@ -728,24 +730,25 @@ int fused_leave(fdes_plan* pl, bool propagated)
 }
 
 // incomingWave, src/multisliceSimulation.cu:563-591
-int incoming_wave(fdes_plan* pl, int k)
+int incoming_wave(fdes_plan* pl, int k, float2* psi = nullptr) // psi: where the wave goes (default: the plan's PSI)
 {
+    float2* const PSI = psi ? psi : pl->PSI;
     fdes_ctx* c = pl->ctx;
     const fdes_params& p = pl->p;
-    HIPCHK(c, k_fill(pl->PSI, pl->m12, 1.f, 0.f, c->stream));
+    HIPCHK(c, k_fill(PSI, pl->m12, 1.f, 0.f, c->stream));
     pl->wave_bl = !(p.mode == 2 && p.doBeamTilt);
     if (p.mode == 2) {
-        HIPCHK(c, k_lens(pl->PSI, pl->kp, p.defoci[k], c->stream));
-        HIPCHK(c, fft_exec(pl,pl->PSI, true, c->stream));
-        HIPCHK(c, k_fftshift(pl->T, pl->PSI, p.m1, p.m2, c->stream));
-        HIPCHK(c, hipMemcpyAsync(pl->PSI, pl->T, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
-        RC(bandwidth_limit(pl, pl->PSI));
-        HIPCHK(c, k_normalize_to(pl->PSI, pl->m12, sqrtf((float)(p.n1 * p.n2)), pl->scal, c->stream));
+        HIPCHK(c, k_lens(PSI, pl->kp, p.defoci[k], c->stream));
+        HIPCHK(c, fft_exec(pl,PSI, true, c->stream));
+        HIPCHK(c, k_fftshift(pl->T, PSI, p.m1, p.m2, c->stream));
+        HIPCHK(c, hipMemcpyAsync(PSI, pl->T, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream));
+        RC(bandwidth_limit(pl, PSI));
+        HIPCHK(c, k_normalize_to(PSI, pl->m12, sqrtf((float)(p.n1 * p.n2)), pl->scal, c->stream));
     }
-    if (p.doBeamTilt) HIPCHK(c, k_tilt_beam(pl->PSI, pl->kp, p.tiltbeam[2 * k], p.tiltbeam[2 * k + 1], 1, c->stream));
+    if (p.doBeamTilt) HIPCHK(c, k_tilt_beam(PSI, pl->kp, p.tiltbeam[2 * k], p.tiltbeam[2 * k + 1], 1, c->stream));
     if (p.doBeamTilt && (p.mode == 0 || p.mode == 1)) {
-        HIPCHK(c, k_tukey(pl->PSI, pl->kp, c->stream));
-        RC(bandwidth_limit(pl, pl->PSI));
+        HIPCHK(c, k_tukey(PSI, pl->kp, c->stream));
+        RC(bandwidth_limit(pl, PSI));
     }
     return FDES_OK;
 }
@@ -840,51 +843,54 @@ int slice_loop(fdes_plan* pl, int nslices)
 }
 
 // exit-wave post-processing + accumulation (src/crystalMaker.cu:346-366)
-int exit_wave_post(fdes_plan* pl, int k, float weight)
+int exit_wave_post(fdes_plan* pl, int k, float weight, float2* psi = nullptr, float2* acc = nullptr) // psi: the exit wave; acc: the intensity sum it is added to
 {
+    float2* const PSI = psi ? psi : pl->PSI;
+    float2* const I = acc ? acc : pl->I;
     fdes_ctx* c = pl->ctx;
     const fdes_params& p = pl->p;
-    if (pl->want_ew) HIPCHK(c, k_axpy(pl->EW, pl->PSI, pl->m12, weight, c->stream));
+    if (pl->want_ew) HIPCHK(c, k_axpy(pl->EW, PSI, pl->m12, weight, c->stream));
     if (p.mode == 0) {
         // applyLensFunction (src/multisliceSimulation.cu:614-622) + intensityValues + Caxpy
-        HIPCHK(c, fft_exec(pl,pl->PSI, false, c->stream));
-        HIPCHK(c, k_lens(pl->PSI, pl->kp, p.defoci[k], c->stream));
-        HIPCHK(c, fft_exec(pl,pl->PSI, true, c->stream));
-        HIPCHK(c, k_intensity_axpy(pl->I, pl->PSI, pl->m12, 1.f / ((float)pl->m12), weight, c->stream));
+        HIPCHK(c, fft_exec(pl,PSI, false, c->stream));
+        HIPCHK(c, k_lens(PSI, pl->kp, p.defoci[k], c->stream));
+        HIPCHK(c, fft_exec(pl,PSI, true, c->stream));
+        HIPCHK(c, k_intensity_axpy(I, PSI, pl->m12, 1.f / ((float)pl->m12), weight, c->stream));
     } else {
         // diffractionPattern (src/crystalMaker.cu:700-718)
-        if (p.doBeamTilt) HIPCHK(c, k_tilt_beam(pl->PSI, pl->kp, p.tiltbeam[2 * k], p.tiltbeam[2 * k + 1], -1, c->stream));
+        if (p.doBeamTilt) HIPCHK(c, k_tilt_beam(PSI, pl->kp, p.tiltbeam[2 * k], p.tiltbeam[2 * k + 1], -1, c->stream));
         if (p.mode == 1) {
-            HIPCHK(c, k_mask_filter(pl->PSI, pl->kp, c->stream));
-            RC(bandwidth_limit(pl, pl->PSI));
+            HIPCHK(c, k_mask_filter(PSI, pl->kp, c->stream));
+            RC(bandwidth_limit(pl, PSI));
         }
-        HIPCHK(c, fft_exec(pl,pl->PSI, false, c->stream));
-        HIPCHK(c, k_fftshift(pl->T, pl->PSI, p.m1, p.m2, c->stream));
-        HIPCHK(c, k_intensity_axpy(pl->I, pl->T, pl->m12, sqrtf(1.f / ((float)pl->m12)), weight, c->stream));
+        HIPCHK(c, fft_exec(pl,PSI, false, c->stream));
+        HIPCHK(c, k_fftshift(pl->T, PSI, p.m1, p.m2, c->stream));
+        HIPCHK(c, k_intensity_axpy(I, pl->T, pl->m12, sqrtf(1.f / ((float)pl->m12)), weight, c->stream));
     }
     return FDES_OK;
 }
 
 // addNoiseAndMtf, src/crystalMaker.cu:579-613: the summed intensity in pl->I -> image k
-int finalize_measurement(fdes_plan* pl, int k)
+int finalize_measurement(fdes_plan* pl, int k, float2* acc = nullptr) // acc: the summed intensity (default: the plan's I)
 {
+    float2* const I = acc ? acc : pl->I;
     fdes_ctx* c = pl->ctx;
     const fdes_params& p = pl->p;
     const float alpha = 1.f / ((float)(p.m1 * p.m2));
-    HIPCHK(c, fft_exec(pl,pl->I, false, c->stream));
+    HIPCHK(c, fft_exec(pl,I, false, c->stream));
     if (fabsf(p.illangle) > FLT_EPSILON) {
-        if (p.mode == 0) HIPCHK(c, k_spatial_incoherence(pl->I, pl->kp, p.defoci[k], 0, c->stream));
-        if (p.mode == 1 || p.mode == 2) HIPCHK(c, k_spatial_incoherence(pl->I, pl->kp, p.defoci[k], 1, c->stream));
+        if (p.mode == 0) HIPCHK(c, k_spatial_incoherence(I, pl->kp, p.defoci[k], 0, c->stream));
+        if (p.mode == 1 || p.mode == 2) HIPCHK(c, k_spatial_incoherence(I, pl->kp, p.defoci[k], 1, c->stream));
     }
     if (p.pD > FLT_EPSILON) {
-        HIPCHK(c, k_scale(pl->I, pl->m12, alpha, c->stream));
-        HIPCHK(c, fft_exec(pl,pl->I, true, c->stream));
-        HIPCHK(c, k_noise(pl->I, pl->m12, p.pD, (uint32_t)(1 + p.n3), k, c->stream)); // seed 1 + n3, :295
-        HIPCHK(c, fft_exec(pl,pl->I, false, c->stream));
+        HIPCHK(c, k_scale(I, pl->m12, alpha, c->stream));
+        HIPCHK(c, fft_exec(pl,I, true, c->stream));
+        HIPCHK(c, k_noise(I, pl->m12, p.pD, (uint32_t)(1 + p.n3), k, c->stream)); // seed 1 + n3, :295
+        HIPCHK(c, fft_exec(pl,I, false, c->stream));
     }
-    HIPCHK(c, k_mtf(pl->I, pl->kp, alpha, c->stream));
-    HIPCHK(c, fft_exec(pl,pl->I, true, c->stream));
-    HIPCHK(c, k_crop(pl->Jout + (size_t)k * p.n1 * p.n2, pl->I, pl->kp, c->stream));
+    HIPCHK(c, k_mtf(I, pl->kp, alpha, c->stream));
+    HIPCHK(c, fft_exec(pl,I, true, c->stream));
+    HIPCHK(c, k_crop(pl->Jout + (size_t)k * p.n1 * p.n2, I, pl->kp, c->stream));
     return FDES_OK;
 }
 
@@ -945,9 +951,7 @@ int incoming_wave_gang(fdes_plan* pl, int n)
         if (g > 0 && pl->gq[(size_t)g].k == pl->gq[(size_t)g - 1].k) {
             if (hipMemcpyAsync(mine, mine - pl->m12, sizeof(float2) * pl->m12, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rcw = FDES_EGPU;
         } else {
-            pl->PSI = mine;
-            rcw = incoming_wave(pl, pl->gq[(size_t)g].k);
-            pl->PSI = psi0;
+            rcw = incoming_wave(pl, pl->gq[(size_t)g].k, mine);
         }
     }
     return rcw;
@@ -960,16 +964,9 @@ int exit_wave_post_gang(fdes_plan* pl, int n)
     fdes_ctx* c = pl->ctx;
     const fdes_params& p = pl->p;
     if (n <= 1 || pl->want_ew || !pl->gscr) {
-        float2* const psi0 = pl->PSI;
-        float2* const i0 = pl->I;
         int rce = FDES_OK;
-        for (int g = 0; g < n && rce == FDES_OK; g++) {
-            pl->PSI = psi0 + (size_t)g * pl->m12;
-            pl->I = i0 + (size_t)pl->gq[(size_t)g].slot * pl->m12;
-            rce = exit_wave_post(pl, pl->gq[(size_t)g].k, pl->gq[(size_t)g].w);
-        }
-        pl->PSI = psi0;
-        pl->I = i0;
+        for (int g = 0; g < n && rce == FDES_OK; g++)
+            rce = exit_wave_post(pl, pl->gq[(size_t)g].k, pl->gq[(size_t)g].w, pl->PSI + (size_t)g * pl->m12, pl->I + (size_t)pl->gq[(size_t)g].slot * pl->m12);
         return rce;
     }
     GangPar dk, wt;
@@ -1013,13 +1010,9 @@ int finalize_gang(fdes_plan* pl)
     bool in_order = n > 1 && n <= 16 && pl->gscr != nullptr;
     for (int q = 0; q < n && in_order; q++) in_order = pl->gfinal[(size_t)q].second == q;
     if (!in_order) {
-        float2* const i0 = pl->I;
         int rcf = FDES_OK;
-        for (size_t q = 0; q < pl->gfinal.size() && rcf == FDES_OK; q++) {
-            pl->I = i0 + (size_t)pl->gfinal[q].second * pl->m12;
-            rcf = finalize_measurement(pl, pl->gfinal[q].first);
-        }
-        pl->I = i0;
+        for (size_t q = 0; q < pl->gfinal.size() && rcf == FDES_OK; q++)
+            rcf = finalize_measurement(pl, pl->gfinal[q].first, pl->I + (size_t)pl->gfinal[q].second * pl->m12);
         return rcf;
     }
     GangPar dk, kk;
@@ -1051,8 +1044,6 @@ int gang_flush(fdes_plan* pl)
     fdes_ctx* c = pl->ctx;
     if (n > 0) {
         RC(incoming_wave_gang(pl, n));
-        float* const xyz0 = pl->xyzFP_d;
-        const AtomBins bins0 = pl->bins;
         if (pl->nAt > 0) {
             // tilt, jitter and binning of all members in one launch each (geometry.hip, *_gang): what config_atoms does
             // member by member, to the bit
@@ -1076,14 +1067,8 @@ int gang_flush(fdes_plan* pl)
             BinGeom bg{pl->p.m1, pl->p.m2, pl->p.m3, pl->nZ, pl->p.d1, pl->p.d2, pl->p.d3};
             HIPCHK(c, geom_bin_atoms_gang(pl->gxyzFP, pl->spec_d, pl->occ_d, pl->nAt, n, bg, pl->bins, pl->seg_stride, pl->rowstart_stride, c->stream));
         } else
-        for (int g = 0; g < n; g++) {
-            pl->xyzFP_d = pl->gxyzFP + (size_t)g * 3 * (size_t)pl->nAt;
-            pl->bins = pl->gbins[(size_t)g];
-            const int rc = config_atoms(pl, pl->gq[(size_t)g].k, pl->gq[(size_t)g].j, false);
-            pl->xyzFP_d = xyz0;
-            pl->bins = bins0;
-            RC(rc);
-        }
+        for (int g = 0; g < n; g++)
+            RC(config_atoms(pl, pl->gq[(size_t)g].k, pl->gq[(size_t)g].j, false, pl->gxyzFP + (size_t)g * 3 * (size_t)pl->nAt, &pl->gbins[(size_t)g]));
         // which slices hold atoms: one question (n small copies, ONE host wait) for the whole gang; the rules of
         // config_atoms for when a dense specimen is no longer asked, counted per member
         bool have_all = false;
