@@ -1673,9 +1673,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     if (nlanes > 1 && !c->is_lane_ctx) {
         for (int l = 1; l < nlanes; l++) {
             fdes_ctx* lc = nullptr;
-            int prio = nlanes >= 3 ? l % 3 : 0;
-            if (const char* e = std::getenv("FDES_EXP_LANE_PRIO")) { if ((int)std::strlen(e) > l && e[l] >= '0' && e[l] <= '2') prio = e[l] - '0'; } // experiment: priority class per lane, e.g. "0120"
-            PLCHK(create_ctx(&lc, c->device, prio));
+            PLCHK(create_ctx(&lc, c->device, nlanes >= 3 ? l % 3 : 0)); // (every assignment of the three classes to a fourth lane measured the same)
             lc->is_lane_ctx = true;
             // frozen here: fft, lanes, pass_threads (they shape the lane plan); the others are read through owner_ctx()
             lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad; lc->split = pl->split ? 1 : 0; lc->batch = c->batch > 1 ? c->batch : 0; lc->gang = pl->gang; lc->walk = c->walk;
