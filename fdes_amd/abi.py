@@ -167,6 +167,7 @@ PROTOTYPES = [
     ("fdes_plan_begin_measurement", C.c_int, [_vp, C.c_int]),
     ("fdes_plan_run_config", C.c_int, [_vp, C.c_int, C.c_int, C.c_float]),
     ("fdes_plan_end_measurement", C.c_int, [_vp, C.c_int]),
+    ("fdes_plan_run_measurements", C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     ("fdes_plan_intensity_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
     ("fdes_plan_copy_intensity", C.c_int, [_vp, _vp, C.c_int]),
     ("fdes_plan_copy_intensity_real", C.c_int, [_vp, _vp, C.c_int]),

@@ -249,6 +249,13 @@ class Plan:
     def end_measurement(self, k):
         self._c(self.lib.fdes_plan_end_measurement(self.h, k))
 
+    def run_measurements(self, ks):
+        """Complete measurements `ks` (every configuration, detector chain); a series with one configuration per
+        measurement runs in gangs of measurements."""
+        ks = [int(k) for k in ks]
+        arr = (C.c_int * max(len(ks), 1))(*ks)
+        self._c(self.lib.fdes_plan_run_measurements(self.h, arr, len(ks)))
+
     def sync(self):
         self._c(self.lib.fdes_plan_sync(self.h))
 

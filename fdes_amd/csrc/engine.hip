@@ -2210,6 +2210,46 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
 
 // ------------------------------- buildMeasurements ---------------------------------------------
 
+// Complete measurements ks[0 .. n) - every configuration of each, detector chain included - with the images left in the
+// plan's stack.  A series with one configuration per measurement is dealt to the lanes in blocks of `gang` measurements,
+// each block one gang (own incoming wave, tilt and intensity slot per member), its images finished behind it on that
+// lane; otherwise one measurement after the other through the plan API (whose gangs are the configurations of a k).
+int fdes_plan_run_measurements(fdes_plan* pl, const int* ks, int n)
+{
+    if (!live_plan(pl) || pl->is_lane || n < 0 || (n > 0 && !ks)) return FDES_EINVAL;
+    for (int i = 0; i < n; i++) if (ks[i] < 0 || ks[i] >= pl->p.n3) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int count = pl->p.frPh > 0 ? pl->p.frPh : 1;
+    const float alpha = 1.f / ((float)count); // src/crystalMaker.cu:302-304
+    int rc = FDES_OK;
+    if (!pl->gang_k || pl->want_ew) {
+        for (int i = 0; i < n && rc == FDES_OK; i++) {
+            rc = fdes_plan_begin_measurement(pl, ks[i]);
+            for (int j = 0; j < count && rc == FDES_OK; j++) rc = fdes_plan_run_config(pl, ks[i], j, alpha);
+            if (rc == FDES_OK) rc = fdes_plan_end_measurement(pl, ks[i]);
+        }
+        return rc;
+    }
+    RC(gang_flush_all(pl));
+    const int G = pl->gang, nl = (int)pl->lanes.size() + 1;
+    for (fdes_plan* l : pl->lanes) l->Jout = pl->J;
+    for (int i0 = 0, b = 0; i0 < n && rc == FDES_OK; i0 += G, b++) {
+        fdes_plan* lp = (b % nl) ? pl->lanes[(size_t)(b % nl) - 1] : pl;
+        const int i1 = i0 + G < n ? i0 + G : n;
+        for (int i = i0; i < i1 && rc == FDES_OK; i++) {
+            if (k_fill(lp->I + (size_t)(i - i0) * lp->m12, lp->m12, 0.f, 0.f, lp->ctx->stream) != hipSuccess) { c->err = "k_fill"; rc = FDES_EGPU; }
+            lp->gq.push_back({ks[i], 0, alpha, i - i0});
+            lp->gfinal.push_back({ks[i], i - i0});
+        }
+        if (rc == FDES_OK) rc = gang_flush(lp);
+        if (rc != FDES_OK && lp != pl) c->err = "lane: " + lp->ctx->err;
+        if (rc == FDES_OK) report_progress(pl, (int64_t)i1, (int64_t)n, false);
+    }
+    if (rc == FDES_OK) rc = fdes_plan_sync(pl);
+    return rc;
+}
+
 int fdes_build_measurements(fdes_ctx* c, const fdes_params* p, const fdes_atoms* a, float* image, float* potential, float* exitwave)
 {
     if (!live_ctx(c) || !image) return FDES_EINVAL;
@@ -2225,23 +2265,9 @@ int fdes_build_measurements(fdes_ctx* c, const fdes_params* p, const fdes_atoms*
     }
     int rc = FDES_OK;
     if (pl->gang_k && !exitwave) {
-        // a series with one configuration per measurement: blocks of `gang` measurements are dealt to the lanes, each block
-        // one gang (own incoming wave, tilt and intensity slot per member), its images finished behind it on that lane
-        const int G = pl->gang, nl = (int)pl->lanes.size() + 1;
-        for (fdes_plan* l : pl->lanes) l->Jout = pl->J;
-        for (int k0 = 0, b = 0; k0 < pl->p.n3 && rc == FDES_OK; k0 += G, b++) {
-            fdes_plan* lp = (b % nl) ? pl->lanes[(size_t)(b % nl) - 1] : pl;
-            const int k1 = k0 + G < pl->p.n3 ? k0 + G : pl->p.n3;
-            for (int k = k0; k < k1 && rc == FDES_OK; k++) {
-                if (k_fill(lp->I + (size_t)(k - k0) * lp->m12, lp->m12, 0.f, 0.f, lp->ctx->stream) != hipSuccess) { c->err = "k_fill"; rc = FDES_EGPU; }
-                lp->gq.push_back({k, 0, alpha, k - k0});
-                lp->gfinal.push_back({k, k - k0});
-            }
-            if (rc == FDES_OK) rc = gang_flush(lp);
-            if (rc != FDES_OK && lp != pl) c->err = "lane: " + lp->ctx->err;
-            if (rc == FDES_OK) report_progress(pl, (int64_t)k1, (int64_t)pl->p.n3, false);
-        }
-        if (rc == FDES_OK) rc = fdes_plan_sync(pl);
+        std::vector<int> ks((size_t)pl->p.n3);
+        for (int k = 0; k < pl->p.n3; k++) ks[(size_t)k] = k;
+        rc = fdes_plan_run_measurements(pl, ks.data(), pl->p.n3);
     } else
     for (int k = 0; k < pl->p.n3 && rc == FDES_OK; k++) {
         rc = fdes_plan_begin_measurement(pl, k);

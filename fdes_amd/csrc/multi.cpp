@@ -86,7 +86,15 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
         plans[(size_t)r] = rc == FDES_OK ? pl : nullptr;
         const Part q = part_of(total, ngpu, r);
         std::vector<float> mine;
-        for (int k = 0; k < n3; k++) {
+        // one configuration per measurement (a tilt / defocus series without frozen phonons): no k is split, this GPU's
+        // measurements are complete by themselves and go through the engine in one call (gangs of measurements)
+        const bool whole = count == 1 && !exitwave;
+        if (whole && rc == FDES_OK && q.hi > q.lo) {
+            std::vector<int> ks;
+            for (int i = q.lo; i < q.hi; i++) ks.push_back(i);
+            rc = fdes_plan_run_measurements(pl, ks.data(), (int)ks.size());
+        }
+        for (int k = 0; k < n3 && !whole; k++) {
             const bool split = last[(size_t)k] > first[(size_t)k];
             const bool in_span = r >= first[(size_t)k] && r <= last[(size_t)k];
             const bool owner = first[(size_t)k] == r;

@@ -37,6 +37,13 @@ def run_sharded(plan, n3, count, rank=0, world=1, reduce_fn=None):
     images this rank finalised."""
     mine = partition(n3, count, world, rank)
     own, ranks_of = owners(n3, count, world)
+    if count == 1 and hasattr(plan, "run_measurements"):
+        # one configuration per measurement: no k is split, this rank's measurements are complete by themselves and go
+        # through the engine in one call (gangs of measurements, DESIGN 4.2)
+        ks = [k for (k, _) in mine]
+        if ks:
+            plan.run_measurements(ks)
+        return ks
     weight = float(np.float32(1.0) / np.float32(count))  # alpha of src/crystalMaker.cu:302-304 is a float32
     done = []
     by_k = {}

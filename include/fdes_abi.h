@@ -162,6 +162,11 @@ int fdes_plan_begin_measurement(fdes_plan* plan, int k);
 int fdes_plan_run_config(fdes_plan* plan, int k, int j, float weight);
 /* addNoiseAndMtf (:372, :579-613) -> J[k]. */
 int fdes_plan_end_measurement(fdes_plan* plan, int k);
+/* Complete measurements ks[0 .. n): all their configurations with the weight 1 / count and the detector chain; the images
+ * are in the plan's stack afterwards (fdes_plan_get_images).  What fdes_build_measurements runs; a series with ONE
+ * configuration per measurement goes through it in gangs of measurements (option "gang"), which the per-k calls above
+ * cannot form.  Not while an exit-wave output is wanted in a gang plan: then it runs one k after the other. */
+int fdes_plan_run_measurements(fdes_plan* plan, const int* ks, int n);
 /* Device pointer of the running intensity sum I (float2[m1*m2], .y = 0) so that the host
  * can reduce it across ranks (RCCL) between run_config and end_measurement. */
 int fdes_plan_intensity_ptr(fdes_plan* plan, void** dev_ptr, size_t* bytes);

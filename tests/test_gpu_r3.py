@@ -401,3 +401,45 @@ def test_qsc_cell_with_vacancies_against_the_oracle(oracle, tmp_path):
     eng.close()
     ref = oracle.build_measurements(hp, at, prec="f64")["image"]
     check(img, ref, None, 2e-5, "SrTiO3 .qsc with vacancies (species 0)")
+
+
+def test_run_measurements_and_sharded_series():
+    """fdes_plan_run_measurements: an arbitrary list of measurements of a series (one configuration each) in gangs, images
+    equal to the per-k calls to the bit; shard.run_sharded hands a rank's measurements to it in one call, and two ranks'
+    image stacks add up to the unsharded result."""
+    from fdes_amd import shard
+    hp, at = S.case_tiny(m=256, m3=6, nz=2, nat=150, n3=7, tilt=True, beam_tilt=True)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0, skip_empty=0)
+    full = eng.build_measurements(hp, at)["image"]
+    pl = eng.plan(hp, at)
+    assert pl.gang() > 1
+    pl.run_measurements([5, 2, 6])
+    got = pl.get_images()
+    assert np.array_equal(got[[5, 2, 6]], full[[5, 2, 6]]) and not got[[0, 1, 3, 4]].any()
+    pl.close()
+    ref = np.zeros_like(full)
+    e0 = fdes_amd.Engine(0, skip_empty=0, gang=0, lanes=1)
+    p0 = e0.plan(hp, at)
+    for k in range(7):
+        p0.begin_measurement(k)
+        p0.run_config(k, 0, 1.0)
+        p0.end_measurement(k)
+    ref = p0.get_images()
+    p0.close(); e0.close()
+    assert np.array_equal(ref, full)
+    stacks = []
+    for rank in range(2):
+        plr = eng.plan(hp, at)
+        done = shard.run_sharded(plr, 7, 1, rank, 2, reduce_fn=None)
+        assert done == [k for (k, _) in shard.partition(7, 1, 2, rank)]
+        stacks.append(plr.get_images())
+        plr.close()
+    eng.close()
+    assert np.array_equal(stacks[0] + stacks[1], full)
+    # the in-process multi-GPU driver hands every GPU's measurements over the same way (two workers on one device here)
+    multi = fdes_amd.build_measurements_multi([0, 0], hp, at)
+    e1 = fdes_amd.Engine(0)          # engine defaults on both sides (skip_empty on)
+    one = e1.build_measurements(hp, at)["image"]
+    e1.close()
+    assert relerr(multi, one) < 2e-6
