@@ -1372,7 +1372,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "fft")) { if (value < 0 || value > 2) return FDES_EINVAL; c->opt_fft = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "graph")) { c->opt_graph = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "seed")) { c->seed = (uint32_t)value; return FDES_OK; }
-    if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 64 && value != 65 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "pass_threads")) { if (value != 0 && value != 1 && value != 64 && value != 65 && value != 128 && value != 256 && value != 512 && value != 513) return FDES_EINVAL; c->pass_threads = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "split")) { if (value < -1 || value > 1) return FDES_EINVAL; c->split = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "gang")) { if (value < -1 || value > 16) return FDES_EINVAL; c->gang = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "batch")) { if (value < -1 || value > 8) return FDES_EINVAL; c->batch = (int)value; return FDES_OK; }
@@ -1571,7 +1571,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         // up to 1024^2 a pass is as long as its slowest workgroup: one row per thread, four rows per workgroup
         const bool small = m1 <= 1024 && m2 <= 1024;
         const bool wave_len = m1 == 2048 || m2 == 2048 || m1 == 1024 || m2 == 1024;
-        if ((c->pass_threads == 64 || c->pass_threads == 65) && (wave_pass_supported_len(m1) || wave_pass_supported_len(m2))) pl->wg = c->pass_threads; // one wave per row where the row length has such a kernel
+        if ((c->pass_threads == 64 || c->pass_threads == 65 || c->pass_threads == 128) && (wave_pass_supported_len(m1) || wave_pass_supported_len(m2))) pl->wg = c->pass_threads; // one wave per row where the row length has such a kernel
         else if (c->pass_threads == 512) pl->wg = 512;
         // 2048- and 1024-point rows: one wave per row (fft_wave.hip: one LDS exchange per transform, no barrier inside it; headline
         // +4 ... +6 % over 256 threads x 2 rows, 1024^2 +5 % over one row per thread, A/B on one box; shorter rows of a mixed
@@ -2105,7 +2105,7 @@ int fdes_fft2d_host(fdes_ctx* c, float* data, int m1, int m2, int inverse, int b
     Fft2D f;
     std::string ferr;
     if (f.create(m1, m2, backend, c->stream, &ferr) != 0) { f.destroy(); c->err = "FFT plan: " + ferr; return FDES_EGPU; }
-    if (c->pass_threads == 64 || c->pass_threads == 65) f.wg = c->pass_threads;
+    if (c->pass_threads == 64 || c->pass_threads == 65 || c->pass_threads == 128) f.wg = c->pass_threads;
     float2* d = nullptr;
     const size_t bytes = sizeof(float2) * (size_t)m1 * m2;
     hipError_t e = hipMalloc((void**)&d, bytes);
@@ -2160,7 +2160,7 @@ int fdes_bench_pass(fdes_ctx* c, int n, int pre, int mid, int post, int store_t,
         A.nspecies = 1; A.species_stride = m12; A.scale = 1.f; A.mindim = n;
         A.walk = c->walk;
         if (c->bench_pitch) { A.pitch_in = n + c->bench_pitch; A.pitch_out = (store_t ? n * c->bench_tall : n) + c->bench_pitch; }
-        A.wg = (c->pass_threads == 64 || c->pass_threads == 65) ? c->pass_threads : (c->pass_threads == 256 ? 256 : ((c->pass_threads == 513 || c->pass_threads == 1) && n <= 2048 ? 1 : 512));
+        A.wg = (c->pass_threads == 64 || c->pass_threads == 65 || c->pass_threads == 128) ? c->pass_threads : (c->pass_threads == 256 ? 256 : ((c->pass_threads == 513 || c->pass_threads == 1) && n <= 2048 ? 1 : 512));
         A.stagger = c->stagger;
         if (c->bench_band) { // micro-benchmark of the band-limit bookkeeping: bit 0 live rows only, bit 1 dead loads, bit 2 dead stores
             A.band = n * n;

@@ -105,6 +105,7 @@ void lds_fft_twiddles(int n, float* tw0, float* tw1);
 
 // one-wave-per-row passes (fft_wave.hip)
 bool wave_pass_supported_len(int n);
+bool wave_pass_preferred(int n, int pre, int mid, int post, bool store_transposed);
 hipError_t wave_pass(int n, int pre, int mid, int post, bool store_transposed, const PassArgs& a, hipStream_t st);
 
 // LDS-resident mixed-radix passes for row lengths 2^a 3^b 5^c in [256, 2048] that are not powers of two (fft_gen.hip);

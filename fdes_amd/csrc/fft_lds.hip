@@ -796,6 +796,7 @@ bool lds_fft_supported_len(int n) { return n == 256 || n == 512 || n == 1024 || 
 int lds_fft_rows_per_block(int n, int wg)
 {
     if (gen_pass_supported_len(n)) return gen_pass_rows(n);
+    if (wg == 128) return n == 2048 ? 8 : ((wave_pass_supported_len(n) || n <= 1024) ? 4 : 256 * 2 * 16 / n);
     if (wg == 64 || wg == 65) return (wave_pass_supported_len(n) || n <= 1024) ? 4 : 256 * 2 * 16 / n; // shorter rows: one row per thread, four rows per workgroup
     return wg == 1 ? 4 : (wg == 256 ? 256 * 2 : 512 * 2) * 16 / n;
 }
@@ -827,7 +828,8 @@ hipError_t lds_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
         if (a.band_L != n / 3) a.skip_dead_loads = 0; // the kernel's column classes assume the band of a square grid
     }
     if (gen_pass_supported_len(n)) return gen_pass(n, pre, mid, post, st_t, a, st);
-    if (a.wg == 64 || a.wg == 65) {
+    if (a.wg != 65 && a.walk <= 1 && wave_pass_preferred(n, pre, mid, post, st_t)) { a.wg = 64; return wave_pass(n, pre, mid, post, st_t, a, st); }
+    if (a.wg == 64 || a.wg == 65 || a.wg == 128) {
         if (wave_pass_supported_len(n)) return wave_pass(n, pre, mid, post, st_t, a, st);
         a.wg = n <= 1024 ? 1 : 256; // rows without such a kernel: one row per thread up to 1024 points, else two rows per thread
     }

@@ -123,15 +123,17 @@ template <int P, bool INV> __device__ __forceinline__ void rP(cf (&a)[P])
 // (P rows of 64 + 1 elements: the stride-65 writes of a 16-lane group fall on distinct banks, the reads are contiguous)
 // or the row in natural order for the staged transposed store; regions are ROWP apart, ROWP = 8 (mod 32) elements, so
 // that the 4 rows x 8 columns a half-wave reads for the transposed store fall on 64 distinct banks.
-template <int N> struct WaveGeo {
+// RR = 8 (2048-point rows, PassArgs::wg = 128): eight waves = eight rows, 64-byte segments, one workgroup per CU; the
+// half-wave of the staged store then reads 8 rows x 4 columns, regions 4 (mod 32) elements apart.
+template <int N, int RR = 4> struct WaveGeo {
     static constexpr int P = N / 64;
-    static constexpr int R = 4;
+    static constexpr int R = RR;
     static constexpr int THR = 64 * R;
     static constexpr int XROW = P * 65;
-    static constexpr int ROWP = ((XROW + 31) / 32) * 32 + 8;
+    static constexpr int ROWP = ((XROW + 31) / 32) * 32 + 32 / R;
     static constexpr int NB = P / 8;       // twiddle k = NB a + b
     static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)ROWP * R + 64 + 512; // + the sine / cosine table (FDES_W_SINCOS_TAB)
-    static_assert(XROW >= N && ROWP % 32 == 8, "region layout");
+    static_assert(XROW >= N && ROWP % 32 == 32 / R && (R == 4 || R == 8), "region layout");
 };
 
 // base powers of the stage twiddle w = W_N^t of lane t, and (P = 32) the radix-2 twiddle W_64^(t mod 32)
@@ -487,25 +489,30 @@ __device__ __forceinline__ int live_cols(int i2, int md2)
 // its stores drain while the next group is transformed (software pipeline with the register file as the landing zone).
 // Half-size LDS regions (wave_fft HX; the staged transposed store also goes re / im): 4 N bytes of LDS per row, so that
 // four workgroups = sixteen rows fit on a CU where the registers allow it (<= 128: the one-operand passes at 2048 points).
-// FDES_W_HALFX is a mask of the passes built that way: 1 = band limit (P4), 2 = propagator (P6)
+// FDES_W_HALFX is a mask of the passes built that way: 1 = band limit (P4), 2 = propagator (P6) at 2048 points (measured
+// 2-6 % slower there: two workgroups per CU fit anyway); 4 = P4, 8 = P6 at 4096 points, where a full-size
+// region (33 KiB per row) admits ONE workgroup per CU, whose load, transform and store phases then run strictly one after
+// the other, and half-size regions two (66.7 KiB each, <= 256 registers): P4 65.4 -> 53.2 us, P6 67.5 -> 54.4 us (round 4,
+// tools/bench_hx4096.py) - the default for these two passes at 4096 points, whatever kernels the other passes use.
 #ifndef FDES_W_HALFX
-#define FDES_W_HALFX 0
+#define FDES_W_HALFX 12
 #endif
 template <int N, int MID, bool PIPE> constexpr bool whalfx()
 {
-    return N == 2048 && !PIPE && (((FDES_W_HALFX & 1) && MID == MID_MASK) || ((FDES_W_HALFX & 2) && MID == MID_PTAB));
+    return ((N == 2048 && !PIPE && (((FDES_W_HALFX & 1) && MID == MID_MASK) || ((FDES_W_HALFX & 2) && MID == MID_PTAB))) ||
+            (N == 4096 && !PIPE && (((FDES_W_HALFX & 4) && MID == MID_MASK) || ((FDES_W_HALFX & 8) && MID == MID_PTAB))));
 }
 template <int N, int MID, bool PIPE> constexpr size_t wlds_bytes()
 {
     return whalfx<N, MID, PIPE>() ? sizeof(float) * (size_t)WaveGeo<N>::ROWP * WaveGeo<N>::R + 64 : WaveGeo<N>::LDS_BYTES;
 }
 
-template <int N, int PRE, int MID, int POST, bool STORE_T, bool PIPE>
+template <int N, int PRE, int MID, int POST, bool STORE_T, bool PIPE, int RR = 4>
 __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ lds)
 {
-    using G_ = WaveGeo<N>;
+    using G_ = WaveGeo<N, RR>;
     constexpr int P = G_::P, R = G_::R, THR = G_::THR;
-    constexpr bool HX = whalfx<N, MID, PIPE>();
+    constexpr bool HX = RR == 4 && whalfx<N, MID, PIPE>();
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), t = tid & 63;
     cf* __restrict__ xr = HX ? reinterpret_cast<cf*>(reinterpret_cast<float*>(lds) + w * G_::ROWP) : lds + w * G_::ROWP;
@@ -734,7 +741,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
             wave_fence();
         }
         if constexpr (MID == MID_MULPSI && !PRE_B && PIPE) wload_row<N>(b, in1, t, (A.skip_dead_loads & 2) != 0);
-        if constexpr (MID == MID_PTAB && !PV_HELD && !PIPE) {
+        if constexpr (MID == MID_PTAB && !PV_HELD && !PIPE && !(HX && N > 2048)) {
             const cf* __restrict__ pcol = reinterpret_cast<const cf*>(A.pcol);
 #pragma unroll
             for (int l = 0; l < P; l++) pv[l] = pcol[t + 64 * l];
@@ -771,7 +778,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
 #pragma unroll
             for (int l = 0; l < P; l++) {
                 const bool live = (l < P / 2) ? (t <= tlo - 64 * l) : (t >= thi - 64 * l);
-                const cf wv = cmul3(pr, (!PV_HELD && PIPE) ? reinterpret_cast<const cf*>(A.pcol)[t + 64 * l] : pv[l]); // (table value at the point of use: it sits in the caches)
+                const cf wv = cmul3(pr, (!PV_HELD && (PIPE || (HX && N > 2048))) ? reinterpret_cast<const cf*>(A.pcol)[t + 64 * l] : pv[l]); // (table value at the point of use: it sits in the caches)
                 const cf v = cmul3(a[l], wv);
                 a[l] = live ? v : cf{0.f, 0.f};
             }
@@ -859,22 +866,22 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     } while (PIPE && (vb += vstride) < nvirt);
 }
 
-template <int N, int PRE, int MID, int POST, bool STORE_T, bool PIPE>
-__global__ __launch_bounds__(WaveGeo<N>::THR, (N <= 1024 ? (MID == MID_GTABN ? 2 : 4) : (whalfx<N, MID, PIPE>() ? 4 : ((N <= 2048 && !PIPE) ? 2 : 1)))) void k_wpass(PassArgs A)
+template <int N, int PRE, int MID, int POST, bool STORE_T, bool PIPE, int RR = 4>
+__global__ __launch_bounds__((WaveGeo<N, RR>::THR), (N <= 1024 ? (MID == MID_GTABN ? 2 : 4) : (whalfx<N, MID, PIPE>() ? (N <= 2048 ? 4 : 2) : ((N <= 2048 && !PIPE) ? 2 : 1)))) void k_wpass(PassArgs A)
 {
     extern __shared__ cf wlds[];
-    wpass_body<N, PRE, MID, POST, STORE_T, PIPE>(A, wlds);
+    wpass_body<N, PRE, MID, POST, STORE_T, PIPE, RR>(A, wlds);
 }
 
 #undef float2
 #undef make_float2
 
-template <int N, int PRE, int MID, int POST, bool ST, bool PIPE> hipError_t wlaunch(const PassArgs& a, hipStream_t st)
+template <int N, int PRE, int MID, int POST, bool ST, bool PIPE, int RR = 4> hipError_t wlaunch(const PassArgs& a, hipStream_t st)
 {
-    using G_ = WaveGeo<N>;
+    using G_ = WaveGeo<N, RR>;
     static std::atomic<unsigned long long> attr_set{0}; // dynamic-LDS limit: per function and device (fft_lds.hip, launch)
-    auto kern = k_wpass<N, PRE, MID, POST, ST, PIPE>;
-    constexpr size_t kLds = wlds_bytes<N, MID, PIPE>();
+    auto kern = k_wpass<N, PRE, MID, POST, ST, PIPE, RR>;
+    constexpr size_t kLds = (RR == 4) ? wlds_bytes<N, MID, PIPE>() : G_::LDS_BYTES;
     int dev = 0;
     {
         hipError_t e = hipGetDevice(&dev);
@@ -920,9 +927,9 @@ template <int N, int PRE, int MID, int POST, bool ST, bool PIPE> hipError_t wlau
 // (4096-point product pass: its look-ahead could only be requested late in the iteration, and the compiler reuses the
 // landing registers as spill space in between, which tools/check_acc_landing.py cannot tell from a premature read)
 constexpr bool pipe_fits(int n, int mid) { return !(n > 2048 && (mid == MID_GTAB || mid == MID_GTABN || mid == MID_EXPIV_PAIR || mid == MID_PTAB || mid == MID_MULPSI)); }
-template <int N, bool PIPE> hipError_t wdispatch(int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
+template <int N, bool PIPE, int RR = 4> hipError_t wdispatch(int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
 {
-#define CASE(P_, M_, Q_, S_) if (pre == P_ && mid == M_ && post == Q_ && st_t == S_) return wlaunch<N, P_, M_, Q_, S_, PIPE && pipe_fits(N, M_)>(a, st);
+#define CASE(P_, M_, Q_, S_) if (pre == P_ && mid == M_ && post == Q_ && st_t == S_) return wlaunch<N, P_, M_, Q_, S_, PIPE && pipe_fits(N, M_), RR>(a, st);
     CASE(XF_NONE, MID_NONE, XF_NONE, false)
     CASE(XF_NONE, MID_NONE, XF_NONE, true)
     CASE(XF_NONE, MID_SCALE, XF_NONE, true)
@@ -946,6 +953,13 @@ template <int N, bool PIPE> hipError_t wdispatch(int pre, int mid, int post, boo
 } // namespace
 
 bool wave_pass_supported_len(int n) { return n == 1024 || n == 2048 || n == 4096; }
+// passes that run on these kernels whatever workgroup geometry was asked for: the ones with two workgroups per CU at
+// 4096 points (half-size LDS regions, above)
+bool wave_pass_preferred(int n, int pre, int mid, int post, bool st_t)
+{
+    return n == 4096 && st_t && pre == XF_FWD && post == XF_INV && whalfx<4096, MID_MASK, false>() && whalfx<4096, MID_PTAB, false>() &&
+           (mid == MID_MASK || mid == MID_PTAB);
+}
 
 hipError_t wave_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs& a_in, hipStream_t st)
 {
@@ -954,7 +968,7 @@ hipError_t wave_pass(int n, int pre, int mid, int post, bool st_t, const PassArg
     const bool pipe = a.wg == 65 && a.nbatch <= 1;
     switch (n) {
     case 1024: return wdispatch<1024, false>(pre, mid, post, st_t, a, st); // (a pass over 1024 rows is one generation of workgroups: nothing to pipeline)
-    case 2048: return pipe ? wdispatch<2048, true>(pre, mid, post, st_t, a, st) : wdispatch<2048, false>(pre, mid, post, st_t, a, st);
+    case 2048: return pipe ? wdispatch<2048, true>(pre, mid, post, st_t, a, st) : (a.wg == 128 ? wdispatch<2048, false, 8>(pre, mid, post, st_t, a, st) : wdispatch<2048, false>(pre, mid, post, st_t, a, st));
     case 4096: return pipe ? wdispatch<4096, true>(pre, mid, post, st_t, a, st) : wdispatch<4096, false>(pre, mid, post, st_t, a, st);
     default: return hipErrorInvalidValue;
     }

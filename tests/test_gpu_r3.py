@@ -99,13 +99,15 @@ def test_wave_fft_against_numpy(shape, threads):
     eng.close()
 
 
-@pytest.mark.parametrize("threads", [64, 65])
+@pytest.mark.parametrize("threads", [64, 65, 128])
 @pytest.mark.parametrize("m,nz,stagger", [(2048, 1, 0), (2048, 2, 16), (4096, 1, 0), (4096, 2, 8), (1024, 1, 0), (1024, 3, 0)])
 def test_wave_passes_slice_loop(oracle, m, nz, stagger, threads):
     """Every pass of the slice loop on the one-wave-per-row kernels (P1' atoms, P2 with one and two species, the two-slice
     P3, P4, P5, P6, enter / leave), with and without the staggered start: exit wave after an odd number of slices and
     the potential of both members of a pair against the float64 oracle.  phaseGrating src/crystalMaker.cu:507-536,
     forwardPropagation src/multisliceSimulation.cu:538-549."""
+    if threads == 128 and m != 2048:
+        pytest.skip("eight-row workgroups exist for 2048-point rows only")
     hp, at = S.case_tiny(m=m, m3=5 if m <= 2048 else 3, nz=nz, nat=300, tilt=True, seed=41 + nz)
     fdes_amd.consistent(hp)
     q, _ = oracle.sub_sliced(hp)
@@ -123,7 +125,7 @@ def test_wave_passes_slice_loop(oracle, m, nz, stagger, threads):
     eng.close()
 
 
-@pytest.mark.parametrize("threads", [64, 65])
+@pytest.mark.parametrize("threads", [64, 65, 128])
 def test_wave_passes_equal_lanes_graph_and_empty_slices(oracle, threads):
     """One-wave-per-row passes through the whole driver at 2048^2: two lanes, graph replay, frozen phonons, runs of
     empty slices (P^n steps) - image against the float32 oracle."""
