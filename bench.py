@@ -58,6 +58,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FDES_BENCH_DRYRUN", "").startswith("fail:"):
+        # launcher rehearsal of a rank that dies before the rendezvous: that rank exits 3 at once, the others would block
+        if rank == int(os.environ["FDES_BENCH_DRYRUN"][5:]):
+            sys.exit(3)
+        import time
+        time.sleep(300)
+        return
     if os.environ.get("FDES_BENCH_DRYRUN"):
         # launcher rehearsal without a GPU (tests/test_host_cpu.py): every rank reports what it WOULD run
         print(json.dumps({"dryrun": True, "rank": rank, "world": world, "local_rank": local, "gpus_flag": args.gpus,
@@ -285,10 +292,40 @@ def spawn_ranks(n):
                    MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return _reap(procs, float(os.environ.get("FDES_BENCH_DEADLINE_S", "1500")))
+
+
+def _reap(procs, deadline_s, grace_s=10.0, poll_s=0.2):
+    """Wait for the ranks together (what torch.distributed.run does for its workers): the first rank that exits with an
+    error, or the deadline, takes the others down - terminate(), then kill() after a grace period - so that a rank that
+    died before the rendezvous does not leave its siblings blocked in init_process_group or a barrier.  Returns that first
+    non-zero exit code (124 for the deadline), 0 when every rank ended cleanly."""
+    import time
+    t_end = time.monotonic() + deadline_s
     rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            return 0
+        if time.monotonic() > t_end:
+            print(f"bench.py: ranks still running after {deadline_s:.0f} s - stopping them", file=sys.stderr)
+            rc = 124
+            break
+        time.sleep(poll_s)
     for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+        if p.poll() is None:
+            p.terminate()
+    t_kill = time.monotonic() + grace_s
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.0, t_kill - time.monotonic()))
+        except Exception:
+            p.kill()
+            p.wait()
     return rc
 
 

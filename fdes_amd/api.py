@@ -158,6 +158,22 @@ class Engine:
     def set_option(self, key, value):
         _chk(self.lib.fdes_set_option(self.h, key.encode(), int(value)), key)
 
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id made by one rank (fdes_comm_unique_id); hand it to the other ranks."""
+        buf = C.create_string_buffer(128)
+        _chk(abi.load_library().fdes_comm_unique_id(buf), "fdes_comm_unique_id (librccl.so)")
+        return buf.raw
+
+    def comm_create(self, nranks, rank, uid):
+        """This context's rank in an RCCL communicator (fdes_comm_create; blocks until all ranks joined). Returns the handle."""
+        h = C.c_void_p()
+        _chk(self.lib.fdes_comm_create(self.h, int(nranks), int(rank), uid, C.byref(h)), self.err())
+        return h
+
+    def comm_destroy(self, comm):
+        _chk(self.lib.fdes_comm_destroy(comm), "fdes_comm_destroy")
+
     def set_progress(self, fn, min_interval_ms=200):
         """fn(done, total) in slice-propagations, called between configurations of build_measurements; None removes it."""
         self._progress_cb = abi.PROGRESS_FN(lambda _u, d, t: fn(int(d), int(t))) if fn else None  # keep the thunk alive
@@ -294,6 +310,10 @@ class Plan:
     def accumulate_from(self, other):
         """I (and the exit-wave sum) += other's, device to device (fdes_plan_accumulate_from)."""
         self._c(self.lib.fdes_plan_accumulate_from(self.h, other.h))
+
+    def reduce_intensity(self, comm, root):
+        """Sum of the ranks' running intensity sums onto `root` through RCCL (fdes_plan_reduce_intensity); every rank calls it."""
+        self._c(self.lib.fdes_plan_reduce_intensity(self.h, comm, int(root)))
 
     def want_exitwave(self, on=True):
         self._c(self.lib.fdes_plan_want_exitwave(self.h, int(on)))

@@ -7,6 +7,7 @@
 // two grids per slice, :516-517,534-535, and prints to stderr inside the slice loop, :341).
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
+#include <dlfcn.h>
 
 #include <cfloat>
 #include <chrono>
@@ -184,7 +185,8 @@ struct fdes_plan {
     float2* gscr = nullptr;               // [gang][m12] scratch of the members' 2-D transforms outside the slice loop
     std::vector<void*> gang_owned;        // per-member binning arrays of members >= 1
     size_t recs_stride = 0, rowstart_stride = 0, seg_stride = 0;
-    float2* peer_stage = nullptr;   // landing buffer for another GPU's partial sum (fdes_plan_accumulate_from)
+    float2* peer_stage = nullptr;   // landing buffer for another GPU's partial sum (fdes_plan_accumulate_from; receive buffer of fdes_plan_reduce_intensity)
+    float* real_send = nullptr;     // real view of this plan's intensity sum, packed for the way to another GPU (16 MiB instead of 32 at 2048^2)
     bool peer_host_only = false;    // the peer copy was refused once: partial sums are staged through host memory (option "peer_copy" 0 forces it)
     std::vector<float2> peer_host;
     hipEvent_t peer_ev = nullptr;
@@ -361,7 +363,7 @@ int phase_grating(fdes_plan* pl, const float* xyz, const BinGeom& g, int s)
     kp.m3 = g.m3;
     kp.d3 = g.d3;
     for (int z = 0; z < pl->nZ; z++) {
-        if (owner_ctx(pl)->deterministic) HIPCHK(c, geom_deposit_tile(pl->D, pl->bins, s * pl->nZ + z, -1, true, pl->p.imPot, g, c->stream));
+        if (owner_ctx(pl)->deterministic && geom_deposit_tile_fits(g.m1)) HIPCHK(c, geom_deposit_tile(pl->D, pl->bins, s * pl->nZ + z, -1, true, pl->p.imPot, g, c->stream));
         else
         HIPCHK(c, geom_deposit(pl->D, xyz, pl->occ_d, pl->bins, s * pl->nZ + z, g, pl->p.imPot, pl->deposit_blocks, c->stream));
         HIPCHK(c, fft_exec(pl,pl->D, false, c->stream));
@@ -379,7 +381,7 @@ int phase_grating_pair(fdes_plan* pl, const float* xyz, const BinGeom& g, int s0
     fdes_ctx* c = pl->ctx;
     for (int z = 0; z < pl->nZ; z++) {
         const int k0 = s0 * pl->nZ + z, k1 = (s0 + 1 < g.m3) ? (s0 + 1) * pl->nZ + z : -1;
-        if (owner_ctx(pl)->deterministic) HIPCHK(c, geom_deposit_tile(pl->D, pl->bins, k0, k1, false, 0.f, g, c->stream));
+        if (owner_ctx(pl)->deterministic && geom_deposit_tile_fits(g.m1)) HIPCHK(c, geom_deposit_tile(pl->D, pl->bins, k0, k1, false, 0.f, g, c->stream));
         else
         HIPCHK(c, geom_deposit_pair(pl->D, xyz, pl->occ_d, pl->bins, k0, k1, g, pl->deposit_blocks, c->stream));
         HIPCHK(c, fft_exec(pl, pl->D, false, c->stream));
@@ -1410,7 +1412,7 @@ int fdes_plan_destroy(fdes_plan* pl)
     void* ptrs[] = {pl->Z_d, pl->spec_d, pl->xyz0_d, pl->xyzTO_d, pl->xyzK_d, pl->xyzFP_d, pl->dwf_d, pl->occ_d, pl->bins.keys,
                     pl->bins.keys_sorted, pl->bins.vals, pl->bins.order, pl->bins.seg, pl->bins.tmp, pl->bins.recs, pl->bins.recs_sorted, pl->bins.rowstart, pl->D, pl->VH, pl->T, pl->PSI,
                     pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A == pl->C ? nullptr : pl->A, pl->C, pl->C2, pl->E, pl->PSIH,
-                    pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT, pl->peer_stage}; // F aliases C
+                    pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT, pl->peer_stage, pl->real_send}; // F aliases C
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (void* q : pl->gang_owned) if (q) (void)hipFree(q);
     pl->gang_owned = {}; pl->gbins = {}; pl->gseg = {}; pl->gq = {};
@@ -1762,6 +1764,11 @@ int fdes_plan_end_measurement(fdes_plan* pl, int k)
 int fdes_plan_intensity_ptr(fdes_plan* pl, void** dev_ptr, size_t* bytes)
 {
     if (!live_plan(pl) || !dev_ptr) return FDES_EINVAL;
+    // queued gang members are issued and the lanes' partial sums folded into I first (stream-ordered; the caller
+    // synchronises with fdes_plan_sync before touching the memory): an in-place reduce through this pointer would
+    // otherwise miss them, and end_measurement would add them AFTER the reduce
+    HIPCHK(pl->ctx, hipSetDevice(pl->ctx->device));
+    RC(fold_lanes(pl));
     *dev_ptr = pl->I;
     if (bytes) *bytes = sizeof(float2) * pl->m12;
     return FDES_OK;
@@ -1831,7 +1838,7 @@ int fdes_plan_fft_backend(const fdes_plan* pl) { return live_plan(pl) ? pl->fft-
 int fdes_plan_lanes(const fdes_plan* pl) { return live_plan(pl) ? (int)pl->lanes.size() + 1 : FDES_EINVAL; }
 int fdes_plan_gang(const fdes_plan* pl) { return live_plan(pl) ? pl->gang : FDES_EINVAL; }
 int fdes_plan_num_slices(const fdes_plan* pl) { return live_plan(pl) ? pl->p.m3 : FDES_EINVAL; }
-int64_t fdes_plan_empty_queries(const fdes_plan* pl) { return pl ? (pl->top ? pl->top : pl)->empty_queries : 0; }
+int64_t fdes_plan_empty_queries(const fdes_plan* pl) { return live_plan(pl) ? (pl->top ? pl->top : pl)->empty_queries : 0; }
 
 int64_t fdes_plan_slices_done(const fdes_plan* pl)
 {
@@ -1924,48 +1931,156 @@ int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src)
 {
     if (!live_plan(dst) || !live_plan(src) || dst == src || dst->m12 != src->m12) return FDES_EINVAL;
     fdes_ctx *dc = dst->ctx, *sc = src->ctx;
+    const bool forced_host = owner_ctx(dst)->peer_copy == 0; // test option: take the host-staged path even on one device
+    if (forced_host) dst->peer_host_only = true;
+    const bool same = dc->device == sc->device && !forced_host;
     HIPCHK(sc, hipSetDevice(sc->device));
     RC(fold_lanes(src));
+    if (!same) {
+        // the intensity sum travels as its real view (I.y is identically zero): half the bytes over xGMI
+        if (!src->real_send) {
+            std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc vs a capture in another thread
+            RC(dmalloc(sc, &src->real_send, src->m12));
+        }
+        HIPCHK(sc, k_real_pack(src->real_send, src->I, src->m12, sc->stream));
+    }
     if (!src->peer_ev) HIPCHK(sc, hipEventCreateWithFlags(&src->peer_ev, hipEventDisableTiming));
     HIPCHK(sc, hipEventRecord(src->peer_ev, sc->stream));
     HIPCHK(dc, hipSetDevice(dc->device));
     RC(fold_lanes(dst));
     HIPCHK(dc, hipStreamWaitEvent(dc->stream, src->peer_ev, 0));
-    const bool forced_host = owner_ctx(dst)->peer_copy == 0; // test option: take the host-staged path even on one device
-    if (forced_host) dst->peer_host_only = true;
-    const bool same = dc->device == sc->device && !forced_host;
     if (!same && !dst->peer_stage) {
         std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc vs a capture in another thread
         RC(dmalloc(dc, &dst->peer_stage, dst->m12));
     }
     const int nsum = (dst->want_ew && src->want_ew) ? 2 : 1;
-    for (int q = 0; q < nsum; q++) {
+    for (int q = 0; q < nsum; q++) { // q = 0: intensity (float view between devices); q = 1: coherent exit-wave sum (complex)
         float2* acc = q ? dst->EW : dst->I;
-        const float2* part = q ? src->EW : src->I;
-        if (!same) {
-            // xGMI peer copy; when the runtime refuses it (no peer access between the two devices, or the copy itself
-            // fails) the partial sum is staged through host memory instead - slower, never wrong
-            int can = 0;
-            hipError_t pe = hipDeviceCanAccessPeer(&can, dc->device, sc->device);
-            if (pe == hipSuccess && can && !dst->peer_host_only)
-                pe = hipMemcpyPeerAsync(dst->peer_stage, dc->device, part, sc->device, sizeof(float2) * dst->m12, dc->stream);
-            else if (pe == hipSuccess) pe = hipErrorPeerAccessUnsupported;
-            if (pe != hipSuccess) {
-                (void)hipGetLastError();
-                dst->peer_host_only = true;
-                dst->peer_host.resize(dst->m12);
-                HIPCHK(sc, hipSetDevice(sc->device));
-                HIPCHK(sc, hipMemcpyAsync(dst->peer_host.data(), part, sizeof(float2) * dst->m12, hipMemcpyDeviceToHost, sc->stream));
-                HIPCHK(sc, hipStreamSynchronize(sc->stream));
-                HIPCHK(dc, hipSetDevice(dc->device));
-                HIPCHK(dc, hipMemcpyAsync(dst->peer_stage, dst->peer_host.data(), sizeof(float2) * dst->m12, hipMemcpyHostToDevice, dc->stream));
-                HIPCHK(dc, hipStreamSynchronize(dc->stream)); // peer_host is reused by the next sum
-            }
-            part = dst->peer_stage;
+        if (same) {
+            HIPCHK(dc, k_axpy(acc, q ? src->EW : src->I, dst->m12, 1.f, dc->stream));
+            continue;
         }
-        HIPCHK(dc, k_axpy(acc, part, dst->m12, 1.f, dc->stream));
+        const void* part = q ? (const void*)src->EW : (const void*)src->real_send;
+        const size_t bytes = (q ? sizeof(float2) : sizeof(float)) * dst->m12;
+        // xGMI peer copy; when the runtime refuses it (no peer access between the two devices, or the copy itself
+        // fails) the partial sum is staged through host memory instead - slower, never wrong
+        int can = 0;
+        hipError_t pe = hipDeviceCanAccessPeer(&can, dc->device, sc->device);
+        if (pe == hipSuccess && can && !dst->peer_host_only)
+            pe = hipMemcpyPeerAsync(dst->peer_stage, dc->device, part, sc->device, bytes, dc->stream);
+        else if (pe == hipSuccess) pe = hipErrorPeerAccessUnsupported;
+        if (pe != hipSuccess) {
+            (void)hipGetLastError();
+            dst->peer_host_only = true;
+            dst->peer_host.resize(dst->m12);
+            HIPCHK(sc, hipSetDevice(sc->device));
+            HIPCHK(sc, hipMemcpyAsync(dst->peer_host.data(), part, bytes, hipMemcpyDeviceToHost, sc->stream));
+            HIPCHK(sc, hipStreamSynchronize(sc->stream));
+            HIPCHK(dc, hipSetDevice(dc->device));
+            HIPCHK(dc, hipMemcpyAsync(dst->peer_stage, dst->peer_host.data(), bytes, hipMemcpyHostToDevice, dc->stream));
+            HIPCHK(dc, hipStreamSynchronize(dc->stream)); // peer_host is reused by the next sum
+        }
+        if (q) HIPCHK(dc, k_axpy(acc, dst->peer_stage, dst->m12, 1.f, dc->stream));
+        else HIPCHK(dc, k_axpy_real(acc, reinterpret_cast<const float*>(dst->peer_stage), dst->m12, dc->stream));
     }
     HIPCHK(dc, hipStreamSynchronize(dc->stream));
+    return FDES_OK;
+}
+
+// ---- RCCL: the reduction of SURVEY 8e / src/crystalMaker.cu:347-365 as ONE collective ------------------------------
+// librccl.so is resolved at run time (dlopen, like libhdf5 in emd.cpp): the library has no link-time dependency on it, and
+// a host that never creates a communicator never loads it.
+namespace {
+struct Rccl {
+    void* so = nullptr;
+    bool ok = false;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, fdes_comm_id, int) = nullptr; // ncclUniqueId is passed BY VALUE: a 128-byte struct
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl& rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.so) break;
+        }
+        if (!r.so) return;
+        *(void**)(&r.GetUniqueId) = dlsym(r.so, "ncclGetUniqueId");
+        *(void**)(&r.CommInitRank) = dlsym(r.so, "ncclCommInitRank");
+        *(void**)(&r.CommDestroy) = dlsym(r.so, "ncclCommDestroy");
+        *(void**)(&r.Reduce) = dlsym(r.so, "ncclReduce");
+        *(void**)(&r.GetErrorString) = dlsym(r.so, "ncclGetErrorString");
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Reduce && r.GetErrorString;
+    });
+    return r;
+}
+} // namespace
+
+struct fdes_comm {
+    fdes_ctx* ctx = nullptr;
+    void* comm = nullptr; // ncclComm_t
+    int nranks = 0, rank = -1;
+};
+
+int fdes_comm_unique_id(fdes_comm_id* id)
+{
+    if (!id) return FDES_EINVAL;
+    Rccl& r = rccl();
+    if (!r.ok) return FDES_EUNSUPPORTED;
+    return r.GetUniqueId(id) == 0 ? FDES_OK : FDES_EGPU;
+}
+
+int fdes_comm_create(fdes_ctx* c, int nranks, int rank, const fdes_comm_id* id, fdes_comm** out)
+{
+    if (!c || !id || !out || nranks < 1 || rank < 0 || rank >= nranks) return FDES_EINVAL;
+    *out = nullptr;
+    Rccl& r = rccl();
+    if (!r.ok) { c->err = "librccl.so could not be loaded"; return FDES_EUNSUPPORTED; }
+    HIPCHK(c, hipSetDevice(c->device));
+    void* comm = nullptr;
+    const int e = r.CommInitRank(&comm, nranks, *id, rank); // blocks until every rank has joined
+    if (e != 0 || !comm) { c->err = std::string("ncclCommInitRank: ") + r.GetErrorString(e); return FDES_EGPU; }
+    fdes_comm* k = new fdes_comm;
+    k->ctx = c; k->comm = comm; k->nranks = nranks; k->rank = rank;
+    *out = k;
+    return FDES_OK;
+}
+
+int fdes_comm_destroy(fdes_comm* k)
+{
+    if (!k) return FDES_EINVAL;
+    if (k->comm) {
+        (void)hipSetDevice(k->ctx->device);
+        (void)hipStreamSynchronize(k->ctx->stream);
+        (void)rccl().CommDestroy(k->comm);
+    }
+    delete k;
+    return FDES_OK;
+}
+
+int fdes_plan_reduce_intensity(fdes_plan* pl, fdes_comm* k, int root)
+{
+    if (!live_plan(pl) || !k || !k->comm || root < 0 || root >= k->nranks || pl->ctx != k->ctx) return FDES_EINVAL;
+    fdes_ctx* c = pl->ctx;
+    Rccl& r = rccl();
+    HIPCHK(c, hipSetDevice(c->device));
+    RC(fold_lanes(pl));
+    if (!pl->real_send || (k->rank == root && !pl->peer_stage)) {
+        std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc vs a capture in another thread
+        if (!pl->real_send) RC(dmalloc(c, &pl->real_send, pl->m12));
+        if (k->rank == root && !pl->peer_stage) RC(dmalloc(c, &pl->peer_stage, pl->m12));
+    }
+    HIPCHK(c, k_real_pack(pl->real_send, pl->I, pl->m12, c->stream));
+    float* recv = k->rank == root ? reinterpret_cast<float*>(pl->peer_stage) : pl->real_send; // (only the root's is written)
+    const int e = r.Reduce(pl->real_send, recv, pl->m12, /* ncclFloat32 */ 7, /* ncclSum */ 0, root, k->comm, c->stream);
+    if (e != 0) { c->err = std::string("ncclReduce: ") + r.GetErrorString(e); return FDES_EGPU; }
+    if (k->rank == root) HIPCHK(c, k_real_unpack(pl->I, recv, pl->m12, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return FDES_OK;
 }
 
@@ -1989,7 +2104,7 @@ int fdes_plan_potential(fdes_plan* pl, int s_lo, int s_hi, float* potential)
     return FDES_OK;
 }
 
-int fdes_plan_original_slices(const fdes_plan* pl) { return pl ? (int)(((float)pl->p.m3) * (1.f / (float)pl->ratio)) : FDES_EINVAL; }
+int fdes_plan_original_slices(const fdes_plan* pl) { return live_plan(pl) ? (int)(((float)pl->p.m3) * (1.f / (float)pl->ratio)) : FDES_EINVAL; }
 
 // ------------------------------- stage taps (parity tests) -------------------------------------
 

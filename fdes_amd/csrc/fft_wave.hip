@@ -24,6 +24,10 @@
 #include "fft_lds.h"
 #include "geometry.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "fft_wave.hip uses v_permlane32_swap / v_permlane16_swap (gfx950); this library is written for MI355X only"
+#endif
+
 #include <atomic>
 #include <cmath>
 #include <type_traits>
@@ -475,6 +479,12 @@ __device__ __forceinline__ int live_cols(int i2, int md2)
     return Lr;
 }
 
+// FDES_W_WALK = 1 (experiment, round 4): the kernels of pass_threads = 65 become plain WALKERS - half as many workgroups as
+// the chip has slots, each walking its row groups WITHOUT look-ahead at two waves per SIMD - so that the kernels of two
+// lanes share every CU for their whole life (one workgroup of each) instead of following each other generation by generation.
+#ifndef FDES_W_WALK
+#define FDES_W_WALK 0
+#endif
 #ifndef FDES_W_P5_PREFETCH
 #define FDES_W_P5_PREFETCH 1 // the second operand of the product is requested together with the first (no extra registers: while one operand is in its butterflies the other one only sits)
 #endif
@@ -566,7 +576,8 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     //  the second operand of the current group is then requested at the top of the iteration)
     constexpr bool PRE_B = (MID == MID_MULPSI) && (FDES_W_P5_PREFETCH || PIPE) && !(PIPE && N > 2048);
     constexpr bool PV_HELD = (MID == MID_PTAB) && (FDES_W_PTAB_EARLY || PIPE) && !(PIPE && N > 2048) && !HX;
-    constexpr bool ACC = PIPE && FDES_W_ACC_PREFETCH; // look-ahead operands land in the accumulation registers
+    constexpr bool WALK = PIPE && FDES_W_WALK;
+    constexpr bool ACC = PIPE && FDES_W_ACC_PREFETCH && !WALK; // look-ahead operands land in the accumulation registers
     cf an[LOADS_ROW ? P : 1];
     cf bn[PRE_B ? P : 1];
     float gn[(MID == MID_GTAB) ? P : 1];
@@ -604,7 +615,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
             for (int l = 0; l < P; l++) gn[l] = 0.f;
         }
     };
-    request(row0_of(vb));
+    if constexpr (!WALK) request(row0_of(vb));
     // column factors of the propagator: the same for every row
     cf pv[(MID == MID_PTAB) ? P : 1];
     if constexpr (PV_HELD) {
@@ -618,6 +629,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     unsigned ldt = ldt0;
     if constexpr (PIPE) asm volatile("" : "+s"(ldt)); // per iteration: otherwise the 32-64 scalar row pointers of the transposed store are hoisted out of the loop and spilled
     const int row0 = row0_of(vb);
+    if constexpr (WALK) request(row0);
     const int grow = row0 + w;
     const size_t rbase = (size_t)grow * pin; // wave-uniform
     const cf* __restrict__ in0 = A.in0 ? reinterpret_cast<const cf*>(A.in0) + rbase + zoff_in : nullptr;
@@ -653,8 +665,8 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     }
     // the next group's operands: requested now, consumed one iteration later (4096-point product pass: three operands
     // of 128 registers do not fit beside the temporaries, so the request waits until the product has freed one)
-    constexpr bool LATE_REQ = PIPE && N > 2048 && MID == MID_MULPSI;
-    if constexpr (PIPE && !LATE_REQ) {
+    constexpr bool LATE_REQ = PIPE && !WALK && N > 2048 && MID == MID_MULPSI;
+    if constexpr (PIPE && !LATE_REQ && !WALK) {
         __builtin_amdgcn_sched_barrier(0); // the landed operands are taken before their registers are requested again
         if (vb + vstride < nvirt) request(row0_of(vb + vstride));
         else no_request();
@@ -867,7 +879,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
 }
 
 template <int N, int PRE, int MID, int POST, bool STORE_T, bool PIPE, int RR = 4>
-__global__ __launch_bounds__((WaveGeo<N, RR>::THR), (N <= 1024 ? (MID == MID_GTABN ? 2 : 4) : (whalfx<N, MID, PIPE>() ? (N <= 2048 ? 4 : 2) : ((N <= 2048 && !PIPE) ? 2 : 1)))) void k_wpass(PassArgs A)
+__global__ __launch_bounds__((WaveGeo<N, RR>::THR), (N <= 1024 ? (MID == MID_GTABN ? 2 : 4) : (whalfx<N, MID, PIPE>() ? (N <= 2048 ? 4 : 2) : ((N <= 2048 && (!PIPE || FDES_W_WALK)) ? 2 : 1)))) void k_wpass(PassArgs A)
 {
     extern __shared__ cf wlds[];
     wpass_body<N, PRE, MID, POST, STORE_T, PIPE, RR>(A, wlds);

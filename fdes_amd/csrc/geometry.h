@@ -43,6 +43,8 @@ hipError_t geom_deposit(float2* V, const float* xyz, const float* occ, const Ato
 
 // deterministic deposit from the sorted records (needs geom_bin_atoms(..., with_rows = true)): component x <- segment
 // key0, component y <- segment key1 (-1: none), or with_impot: y = imPot * x; overwrites V (no clearing needed)
+// one whole row of the grid (float2) must fit the LDS tile: rows beyond 20 480 points take the atomic deposit instead
+inline bool geom_deposit_tile_fits(int m1) { return m1 > 0 && sizeof(float2) * (size_t)m1 <= (size_t)160 * 1024; }
 hipError_t geom_deposit_tile(float2* V, const AtomBins& b, int key0, int key1, bool with_impot, float imPot, const BinGeom& g, hipStream_t st);
 hipError_t geom_deposit_pair(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key0, int key1, const BinGeom& g,
                              int blocks, hipStream_t st);

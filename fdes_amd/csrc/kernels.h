@@ -29,6 +29,7 @@ hipError_t k_axpy(float2* y, const float2* x, size_t n, float alpha, hipStream_t
 // real part of a complex grid <-> float grid (the intensity sums are real: collectives move the float view)
 hipError_t k_real_pack(float* dst, const float2* src, size_t n, hipStream_t st);
 hipError_t k_real_unpack(float2* dst, const float* src, size_t n, hipStream_t st);
+hipError_t k_axpy_real(float2* y, const float* x, size_t n, hipStream_t st); // y.x += x
 // Vhat = (first ? 0 : Vhat) + Dhat * g_Z(q) ; Dhat = 0   (projectedPotential_d * divideBySinc * multiplyWith...)
 hipError_t k_filter_accum(float2* Vhat, float2* Dhat, const KP& p, const Kirk& kz, int first, hipStream_t st);
 hipError_t k_filter_accum_tab(float2* Vhat, float2* Dhat, const float* G, size_t n, int first, hipStream_t st);

@@ -64,6 +64,28 @@ __global__ void kk_axpy(float2* __restrict__ y, const float2* __restrict__ x, si
 
 __global__ void kk_real_pack(float* __restrict__ d, const float2* __restrict__ s, size_t n) { GS_LOOP(i, n) d[i] = s[i].x; }
 __global__ void kk_real_unpack(float2* __restrict__ d, const float* __restrict__ s, size_t n) { GS_LOOP(i, n) d[i] = make_float2(s[i], 0.f); }
+// y.x += x: a partial intensity sum arrives as its real view (its imaginary part is identically zero)
+__global__ void kk_axpy_real(float2* __restrict__ y, const float* __restrict__ x, size_t n) { GS_LOOP(i, n) { float2 v = y[i]; v.x += x[i]; y[i] = v; } }
+
+// The Fourier-space filter a deposit grid is multiplied with: Kirkland's f_e(q^2) (three Lorentzians + three Gaussians, q in
+// 1/Angstrom from the frequency indices and the pixel sizes in Angstrom; projectedPotential_d, src/projectedPotential.cu:30-73)
+// x the reference's constant and grid normalisation (`scale`), x the inverse transform of the pixel-wide top-hat along both
+// axes, u / sin u with u = pi i / m (divideBySinc, src/crystalMaker.cu:136-158).  Float32 in the reference's order of
+// operations: ((f_e scale) (x-factor y-factor)).
+__device__ __forceinline__ float potential_filter(int i1, int i2, const KP& p, const Kirk& kz, float d1_angstrom, float d2_angstrom, float scale)
+{
+    const float q1 = ((float)i1) / (d1_angstrom * ((float)p.m1));
+    const float q2 = ((float)i2) / (d2_angstrom * ((float)p.m2));
+    const float qsq = q1 * q1 + q2 * q2;
+    float fe = kz.a0 / (qsq + kz.b0) + kz.c0 * expf(-kz.d0 * qsq);
+    fe += kz.a1 / (qsq + kz.b1) + kz.c1 * expf(-kz.d1 * qsq);
+    fe += kz.a2 / (qsq + kz.b2) + kz.c2 * expf(-kz.d2 * qsq);
+    const float u1 = ((float)i1) / ((float)p.m1) * PI_F;
+    const float u2 = PI_F * (((float)i2) / ((float)p.m2));
+    const float unsinc1 = (u1 + FLT_EPSILON) / (sinf(u1) + FLT_EPSILON);
+    const float unsinc2 = (u2 + FLT_EPSILON) / (sinf(u2) + FLT_EPSILON);
+    return (fe * scale) * (unsinc1 * unsinc2);
+}
 
 // ---- projectedPotential_d (src/projectedPotential.cu:30-73) * divideBySinc (src/crystalMaker.cu:
 // 136-158) * multiplyWithProjectedPotential_d (:160-172) + cublasCaxpy (:532), in Fourier space.
@@ -78,19 +100,7 @@ __global__ void kk_filter_accum(float2* __restrict__ Vh, float2* __restrict__ Dh
     {
         const int j1 = (int)(i % (size_t)p.m1), j2 = (int)(i / (size_t)p.m1);
         const int i1 = iw(j1, p.m1), i2 = iw(j2, p.m2);
-        float qsq = ((float)i1) / (d1 * ((float)p.m1));
-        float Vz = ((float)i2) / (d2 * ((float)p.m2));
-        qsq = qsq * qsq + Vz * Vz;
-        Vz = kz.a0 / (qsq + kz.b0) + kz.c0 * expf(-kz.d0 * qsq);
-        Vz += kz.a1 / (qsq + kz.b1) + kz.c1 * expf(-kz.d1 * qsq);
-        Vz += kz.a2 / (qsq + kz.b2) + kz.c2 * expf(-kz.d2 * qsq);
-        float g = Vz * scale;
-        float y = PI_F;
-        float x = ((float)i1) / ((float)p.m1) * y;
-        x = (x + FLT_EPSILON) / (sinf(x) + FLT_EPSILON);
-        y *= ((float)i2) / ((float)p.m2);
-        x *= (y + FLT_EPSILON) / (sinf(y) + FLT_EPSILON);
-        g *= x;
+        const float g = potential_filter(i1, i2, p, kz, d1, d2, scale);
         const float2 d = Dh[i];
         float2 v = first ? make_float2(0.f, 0.f) : Vh[i];
         v.x += d.x * g;
@@ -141,19 +151,7 @@ __global__ void kk_gtab(float* __restrict__ G, KP p, Kirk kz, int transposed, in
         const int j1 = transposed ? (int)(i / (size_t)p.m2) : (int)(i % (size_t)p.m1);
         const int j2 = transposed ? (int)(i % (size_t)p.m2) : (int)(i / (size_t)p.m1);
         const int i1 = iw(j1, p.m1), i2 = iw(j2, p.m2);
-        float qsq = ((float)i1) / (d1 * ((float)p.m1));
-        float Vz = ((float)i2) / (d2 * ((float)p.m2));
-        qsq = qsq * qsq + Vz * Vz;
-        Vz = kz.a0 / (qsq + kz.b0) + kz.c0 * expf(-kz.d0 * qsq);
-        Vz += kz.a1 / (qsq + kz.b1) + kz.c1 * expf(-kz.d1 * qsq);
-        Vz += kz.a2 / (qsq + kz.b2) + kz.c2 * expf(-kz.d2 * qsq);
-        float g = Vz * scale;
-        float y = PI_F;
-        float x = ((float)i1) / ((float)p.m1) * y;
-        x = (x + FLT_EPSILON) / (sinf(x) + FLT_EPSILON);
-        y *= ((float)i2) / ((float)p.m2);
-        x *= (y + FLT_EPSILON) / (sinf(y) + FLT_EPSILON);
-        G[(transposed && pitch > 0) ? (size_t)j1 * (size_t)pitch + (size_t)j2 : i] = g * x; // pitch: padded rows of the transposed table
+        G[(transposed && pitch > 0) ? (size_t)j1 * (size_t)pitch + (size_t)j2 : i] = potential_filter(i1, i2, p, kz, d1, d2, scale); // pitch: padded rows of the transposed table
     }
 }
 
@@ -200,12 +198,11 @@ __global__ void kk_pick_potential(float2* __restrict__ V, const float2* __restri
 // ---- multiplyElementwise (src/complexMath.cu:44-62): 3-multiply product, f0 = (a, b), f1 = (c, d)
 __device__ __forceinline__ float2 cmul3(float2 f0, float2 f1)
 {
-    const float a = f0.x, b = f0.y;
-    float c = f1.x, d = f1.y;
-    const float k = a * (c + d);
-    d *= a + b;
-    c *= b - a;
-    return make_float2(k - d, k + c);
+    const float a = f0.x, b = f0.y, c = f1.x, d = f1.y;
+    const float shared = a * (c + d);
+    const float sub_re = d * (a + b);
+    const float add_im = c * (b - a);
+    return make_float2(shared - sub_re, shared + add_im);
 }
 __global__ void kk_mul(float2* __restrict__ dst, const float2* __restrict__ f0, const float2* __restrict__ f1, size_t n)
 {
@@ -225,12 +222,12 @@ __global__ void kk_propagator(float2* __restrict__ P, KP p, int transposed)
         const int j1 = transposed ? (int)(i / (size_t)p.m2) : (int)(i % (size_t)p.m1);
         const int j2 = transposed ? (int)(i % (size_t)p.m2) : (int)(i / (size_t)p.m1);
         const int i1 = iw(j1, p.m1), i2 = iw(j2, p.m2);
-        float d3 = p.d3;
-        const float t1 = ((float)(i1) / ((float)p.m1)) * (d3 / p.d1);
-        const float t2 = ((float)(i2) / ((float)p.m2)) * (d3 / p.d2);
-        d3 = p.lambda / d3;
-        d3 = -PI_F * (t1 * t1 + t2 * t2) * d3;
-        float2 v = make_float2(cosf(d3), sinf(d3));
+        // k d3 per axis (k = i / (m d)), then the Fresnel phase -pi lambda d3 k^2 as -pi (k d3)^2 (lambda / d3)
+        const float kd1 = ((float)(i1) / ((float)p.m1)) * (p.d3 / p.d1);
+        const float kd2 = ((float)(i2) / ((float)p.m2)) * (p.d3 / p.d2);
+        const float lambda_over_d3 = p.lambda / p.d3;
+        const float phase = -PI_F * (kd1 * kd1 + kd2 * kd2) * lambda_over_d3;
+        float2 v = make_float2(cosf(phase), sinf(phase));
         if (outside_band(i1, i2, mindim)) v = make_float2(0.f, 0.f);
         v.x *= alpha;
         v.y *= alpha;
@@ -273,10 +270,11 @@ __global__ void kk_lens(float2* __restrict__ psi, KP p, float defocus_k, size_t 
     {
         const int i1 = iw((int)(i % (size_t)p.m1), p.m1);
         const int i2 = -iw((int)(i / (size_t)p.m1), p.m2); // row index points up
-        float nu = (((float)i1) / ((float)p.m1)) * (p.lambda / p.d1);
-        float nu2 = (((float)i2) / ((float)p.m2)) * (p.lambda / p.d2);
-        float phi = atan2f(nu2, nu);
-        nu = sqrtf(nu * nu + nu2 * nu2);
+        // scattering angle (nu, azimuth phi) of this frequency
+        const float nu_x = (((float)i1) / ((float)p.m1)) * (p.lambda / p.d1);
+        const float nu_y = (((float)i2) / ((float)p.m2)) * (p.lambda / p.d2);
+        const float phi = atan2f(nu_y, nu_x);
+        const float nu = sqrtf(nu_x * nu_x + nu_y * nu_y);
         float2 out = make_float2(0.f, 0.f);
         if (nu < p.ObjAp) {
             const float W =
@@ -289,18 +287,18 @@ __global__ void kk_lens(float2* __restrict__ psi, KP p, float defocus_k, size_t 
                                    nu * (1.f / 6.f *
                                          (ab.A5_0 * cosf(6.f * (phi - ab.A5_1)) + ab.R5_0 * cosf(4.f * (phi - ab.R5_1)) +
                                           ab.S5_0 * cosf(2.f * (phi - ab.S5_1)) + ab.C5_0))))));
-            nu2 = p.lambda;
-            float damp = 1.f;
+            // temporal-coherence envelope (image mode only), then the transfer function envelope exp(-2 pi i W / lambda)
+            float envelope = 1.f;
             if (p.mode == 0) {
-                damp = p.defocspread * nu * nu / nu2;
-                damp = expf(-2.f * damp * damp);
+                const float spread = p.defocspread * nu * nu / p.lambda;
+                envelope = expf(-2.f * spread * spread);
             }
-            nu = PI_F;
-            phi = damp * cosf(2.f * nu * (W / nu2));
-            damp = damp * sinf(-2.f * nu * (W / nu2));
+            const float waves = W / p.lambda;
+            const float ctf_re = envelope * cosf(2.f * PI_F * waves);
+            const float ctf_im = envelope * sinf(-2.f * PI_F * waves);
             const float2 v = psi[i];
-            out.x = phi * v.x - damp * v.y;
-            out.y = phi * v.y + damp * v.x;
+            out.x = ctf_re * v.x - ctf_im * v.y;
+            out.y = ctf_re * v.y + ctf_im * v.x;
         }
         psi[i] = out;
     }
@@ -348,14 +346,15 @@ __global__ void kk_tilt_beam(float2* __restrict__ psi, KP p, float tb0, float tb
     GS_LOOP(i, n)
     {
         const int i1 = ow((int)(i % (size_t)p.m1), p.m1), i2 = ow((int)(i / (size_t)p.m1), p.m2);
-        float x2 = p.lambda * ((float)flag);
-        float x1 = ((float)i1) * (p.d1 / x2) * tb1;
-        x2 = ((float)i2) * (p.d2 / x2) * tb0;
-        x1 = 2.f * PI_F * (x1 + x2);
-        x2 = sinf(x1);
-        x1 = cosf(x1);
+        // phase ramp 2 pi (x tilt_x + y tilt_y) / lambda; flag = -1 takes the tilt out again (diffractionPattern)
+        const float signed_lambda = p.lambda * ((float)flag);
+        const float ramp_x = ((float)i1) * (p.d1 / signed_lambda) * tb1;
+        const float ramp_y = ((float)i2) * (p.d2 / signed_lambda) * tb0;
+        const float angle = 2.f * PI_F * (ramp_x + ramp_y);
+        const float sn = sinf(angle);
+        const float cs = cosf(angle);
         const float2 v = psi[i];
-        psi[i] = make_float2(x1 * v.x - x2 * v.y, x2 * v.x + x1 * v.y);
+        psi[i] = make_float2(cs * v.x - sn * v.y, sn * v.x + cs * v.y);
     }
 }
 
@@ -427,19 +426,18 @@ __global__ void kk_spatial(float2* __restrict__ f, KP p, float defocus_k, int dp
     {
         const int i1 = iw((int)(i % (size_t)p.m1), p.m1), i2 = iw((int)(i / (size_t)p.m1), p.m2);
         float damp;
-        if (!dp) {
-            damp = p.lambda;
-            float nusq = (((float)i1) / ((float)p.m1)) * (damp / p.d1);
-            damp = (((float)i2) / ((float)p.m2)) * (damp / p.d2);
-            nusq = nusq * nusq + damp * damp;
-            damp = PI_F * p.illangle * defocus_k;
-            damp = expf(-nusq * damp * damp);
-        } else {
-            float x1 = ((float)i1) * p.d1;
-            float x2 = ((float)i2) * p.d2;
-            x1 = x1 * x1 + x2 * x2;
-            x2 = PI_F * p.illangle / p.lambda;
-            damp = expf(-x2 * x2 * x1);
+        if (!dp) { // image: Gaussian in the scattering angle, width set by the illumination angle and this measurement's defocus
+            const float nu_x = (((float)i1) / ((float)p.m1)) * (p.lambda / p.d1);
+            const float nu_y = (((float)i2) / ((float)p.m2)) * (p.lambda / p.d2);
+            const float nusq = nu_x * nu_x + nu_y * nu_y;
+            const float width = PI_F * p.illangle * defocus_k;
+            damp = expf(-nusq * width * width);
+        } else { // diffraction pattern / CBED: Gaussian in the distance from the origin
+            const float x = ((float)i1) * p.d1;
+            const float y = ((float)i2) * p.d2;
+            const float rsq = x * x + y * y;
+            const float width = PI_F * p.illangle / p.lambda;
+            damp = expf(-width * width * rsq);
         }
         float2 v = f[i];
         v.x *= damp;
@@ -456,13 +454,15 @@ __global__ void kk_mtf(float2* __restrict__ f, KP p, float alpha, size_t gstride
     GS_LOOP(i, n)
     {
         const int i1 = iw((int)(i % (size_t)p.m1), p.m1), i2 = iw((int)(i / (size_t)p.m1), p.m2);
-        float nu1 = ((float)i1) / ((float)p.m1);
-        float nu2 = ((float)i2) / ((float)p.m2);
-        float mtf = sqrtf(nu1 * nu1 + nu2 * nu2);
-        mtf = (p.mtfa * expf(-p.mtfc * mtf) + p.mtfb * expf(-p.mtfd * mtf * mtf));
-        nu1 *= PI_F;
-        nu2 *= PI_F;
-        mtf *= ((sinf(nu1) + FLT_EPSILON) / (nu1 + FLT_EPSILON)) * ((sinf(nu2) + FLT_EPSILON) / (nu2 + FLT_EPSILON));
+        // detector response a exp(-c nu) + b exp(-d nu^2) at the frequency nu (in units of the sampling frequency), times the
+        // transform of the square pixel, sin u / u per axis
+        const float nu_x = ((float)i1) / ((float)p.m1);
+        const float nu_y = ((float)i2) / ((float)p.m2);
+        const float nu = sqrtf(nu_x * nu_x + nu_y * nu_y);
+        const float response = (p.mtfa * expf(-p.mtfc * nu) + p.mtfb * expf(-p.mtfd * nu * nu));
+        const float u_x = nu_x * PI_F;
+        const float u_y = nu_y * PI_F;
+        const float mtf = response * (((sinf(u_x) + FLT_EPSILON) / (u_x + FLT_EPSILON)) * ((sinf(u_y) + FLT_EPSILON) / (u_y + FLT_EPSILON)));
         float2 v = f[i];
         v.x = (v.x * mtf) * alpha;
         v.y = (v.y * mtf) * alpha;
@@ -480,12 +480,12 @@ __global__ void kk_noise(float2* __restrict__ f, size_t n, float dose, uint32_t 
         float2 v = f[i];
         const float fi = v.x * dose;
         if (fi > 1e-2f) {
-            float x = normal(seed, 1u, k, 0u, (uint32_t)i);
-            x *= sqrtf(1 - expf(-fi / 0.777134f));
-            x += 2.f * sqrtf(fi + 0.375f) - 0.25f / sqrtf(fi);
-            x = roundf(0.25f * x * x - 0.375f);
-            if (x < FLT_MIN) x = 0.f;
-            v.x = x / dose;
+            // a deviate in the variance-stabilised (Anscombe) domain around the transform of the expected count, back to counts
+            const float deviate = normal(seed, 1u, k, 0u, (uint32_t)i) * sqrtf(1 - expf(-fi / 0.777134f));
+            const float anscombe = deviate + (2.f * sqrtf(fi + 0.375f) - 0.25f / sqrtf(fi));
+            float counts = roundf(0.25f * anscombe * anscombe - 0.375f);
+            if (counts < FLT_MIN) counts = 0.f;
+            v.x = counts / dose;
             f[i] = v;
         }
     }
@@ -551,6 +551,7 @@ hipError_t k_scale(float2* f, size_t n, float a, hipStream_t st) { LAUNCH(kk_sca
 hipError_t k_axpy(float2* y, const float2* x, size_t n, float a, hipStream_t st) { LAUNCH(kk_axpy, n, st, y, x, n, a); }
 hipError_t k_real_pack(float* d, const float2* s, size_t n, hipStream_t st) { LAUNCH(kk_real_pack, n, st, d, s, n); }
 hipError_t k_real_unpack(float2* d, const float* s, size_t n, hipStream_t st) { LAUNCH(kk_real_unpack, n, st, d, s, n); }
+hipError_t k_axpy_real(float2* y, const float* x, size_t n, hipStream_t st) { LAUNCH(kk_axpy_real, n, st, y, x, n); }
 hipError_t k_filter_accum(float2* Vh, float2* Dh, const KP& p, const Kirk& kz, int first, hipStream_t st)
 {
     LAUNCH(kk_filter_accum, (size_t)p.m1 * p.m2, st, Vh, Dh, p, kz, first);

@@ -2,11 +2,21 @@
 // against the public C-ABI only (what a maintainer of the reference's C++ host would write).  The (k, j) wave
 // propagations of src/crystalMaker.cu:324-367 are independent; the flattened list is block-partitioned over the GPUs
 // exactly as fdes_amd/shard.py does for the one-process-per-GPU launch.  The partial sums of a measurement k that spans
-// GPUs (intensity; the coherent exit-wave sum when asked for) are added on the OWNER's GPU in ascending GPU order: one
-// peer copy over xGMI and one axpy kernel per contributing GPU (fdes_plan_accumulate_from; src/crystalMaker.cu:347-365
-// is the sum being distributed), then the owner applies addNoiseAndMtf.  The potential output (print_level > 0) does
-// not depend on (k, j): its slices are dealt over the GPUs.  Random numbers are keyed on (k, j): the images do not
-// depend on the partition beyond the association order of that one sum.
+// GPUs (intensity; the coherent exit-wave sum when asked for; src/crystalMaker.cu:347-365 is the sum being distributed)
+// end on the OWNER's GPU, which then applies addNoiseAndMtf.  Two ways:
+//   * default: a binary TREE of fdes_plan_accumulate_from calls - in round s = 1, 2, 4 the GPU at offset i (a multiple of
+//     2 s) of the span adds the sum of the GPU at offset i + s: log2(GPUs) rounds of concurrent peer copies over xGMI (the
+//     intensity as its float view, 16 MiB at 2048^2) and add kernels instead of seven serial rounds through the owner; the
+//     association order is fixed by the tree, so the images do not depend on timing;
+//   * FDES_REDUCE=rccl: ONE ncclReduce(sum, float[m1 m2]) to the owner over a communicator created once per
+//     call, for measurements that span ALL GPUs (the frozen-phonon configurations of one image dealt over the node) when
+//     every worker has a device of its own and no exit-wave output is wanted; anything else, and any failure to set the
+//     communicator up, takes the tree.  Not the default: creating a communicator costs more than a whole headline job
+//     (seconds against tens of milliseconds), and RCCL picks the association order.
+// The potential output (print_level > 0) does not depend on (k, j): its slices are dealt over the GPUs.  Random numbers are
+// keyed on (k, j): the images do not depend on the partition beyond the association order of that one sum.
+#include <atomic>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -73,14 +83,36 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
             if (r > last[(size_t)k]) last[(size_t)k] = r;
         }
     }
-    std::vector<fdes_plan*> plans((size_t)ngpu, nullptr); // read by the owner between the two barriers of a split k
+    std::vector<fdes_plan*> plans((size_t)ngpu, nullptr); // read by the adding GPU between the barriers of a split k
     std::vector<int> status((size_t)ngpu, FDES_OK);
     Barrier bar(ngpu);
+    // FDES_REDUCE=rccl: one communicator for the call (one rank per worker; RCCL refuses two ranks on one device)
+    bool want_rccl = false;
+    fdes_comm_id comm_id;
+    {
+        const char* mode = std::getenv("FDES_REDUCE");
+        bool distinct = true;
+        for (int r = 0; r < ngpu; r++)
+            for (int q = 0; q < r; q++) distinct = distinct && devices[r] != devices[q];
+        bool spans_all = false;
+        for (int k = 0; k < n3; k++) spans_all = spans_all || (first[(size_t)k] == 0 && last[(size_t)k] == ngpu - 1);
+        want_rccl = mode && !std::strcmp(mode, "rccl") && distinct && spans_all && !exitwave && fdes_comm_unique_id(&comm_id) == FDES_OK;
+    }
+    std::vector<fdes_comm*> comms((size_t)ngpu, nullptr);
+    std::atomic<int> comm_failures{0}, failed_before_collective{0};
     auto worker = [&](int r) {
         int& rc = status[(size_t)r];
         fdes_ctx* ctx = nullptr;
         fdes_plan* pl = nullptr;
         rc = fdes_create(&ctx, devices[r]);
+        bool rccl = false;
+        if (want_rccl) { // every worker joins or none does: a rank that never calls ncclCommInitRank would block the others
+            if (rc != FDES_OK) comm_failures++;
+            bar.wait();
+            if (comm_failures.load() == 0 && fdes_comm_create(ctx, ngpu, r, &comm_id, &comms[(size_t)r]) != FDES_OK) comm_failures++;
+            bar.wait();
+            rccl = comm_failures.load() == 0;
+        }
         if (rc == FDES_OK) rc = fdes_plan_create(ctx, p, a, &pl);
         if (rc == FDES_OK && exitwave) rc = fdes_plan_want_exitwave(pl, 1);
         plans[(size_t)r] = rc == FDES_OK ? pl : nullptr;
@@ -103,12 +135,21 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
                 rc = fdes_plan_begin_measurement(pl, k);
                 for (int i = jlo; i < jhi && rc == FDES_OK; i++) rc = fdes_plan_run_config(pl, k, i % count, weight);
             }
-            if (split) { // every thread passes both barriers, whatever its state, so that nobody waits for ever
+            if (split && rccl && first[(size_t)k] == 0 && last[(size_t)k] == ngpu - 1) {
+                // one collective; a rank that has failed must not leave the others inside it: all agree first
+                if (rc != FDES_OK) failed_before_collective++;
+                bar.wait();
+                if (failed_before_collective.load() == 0) rc = fdes_plan_reduce_intensity(pl, comms[(size_t)r], first[(size_t)k]);
+                else if (rc == FDES_OK) rc = FDES_EGPU; // a peer failed
+            } else if (split) { // every thread passes every barrier, whatever its state, so that nobody waits for ever
                 if (rc != FDES_OK) plans[(size_t)r] = nullptr;
-                bar.wait(); // the peers' configurations are enqueued; accumulate_from orders behind them with an event
-                if (rc == FDES_OK && owner)
-                    for (int s = first[(size_t)k] + 1; s <= last[(size_t)k] && rc == FDES_OK; s++) // ascending GPU order
-                        rc = plans[(size_t)s] ? fdes_plan_accumulate_from(pl, plans[(size_t)s]) : FDES_EGPU; // a peer failed
+                const int f = first[(size_t)k], n = last[(size_t)k] - f + 1, i = r - f;
+                for (int s = 1; s < n; s <<= 1) { // binary tree over the span, the owner (offset 0) at its root
+                    bar.wait(); // the sources of this round are complete: their configurations resp. their own additions are enqueued / done
+                    if (rc == FDES_OK && in_span && i % (2 * s) == 0 && i + s < n)
+                        rc = plans[(size_t)(f + i + s)] ? fdes_plan_accumulate_from(pl, plans[(size_t)(f + i + s)]) : FDES_EGPU; // a peer failed
+                    if (rc != FDES_OK && plans[(size_t)r]) plans[(size_t)r] = nullptr; // (only an adding GPU can get here: nobody reads its entry in this round)
+                }
                 bar.wait(); // the peers' sums have been read: they may start their next measurement
             }
             if (rc == FDES_OK && owner && exitwave) rc = fdes_plan_get_exitwave(pl, exitwave + 2 * m12 * (size_t)k);
@@ -126,6 +167,7 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
         }
         if (rc != FDES_OK) std::fprintf(stderr, "  FDES: worker %d (device %d) failed with %d: %s\n", r, devices[r], rc, ctx ? fdes_last_error(ctx) : "no context");
         bar.wait(); // nobody destroys a plan that a late accumulate_from of another thread could still name
+        if (comms[(size_t)r]) fdes_comm_destroy(comms[(size_t)r]);
         if (pl) fdes_plan_destroy(pl);
         if (ctx) fdes_destroy(ctx);
     };

@@ -18,6 +18,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden and an export list (fdes_amd/csrc/exports_*.txt): only what this header
+ * declares is a dynamic symbol. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define FDES_ABI_VERSION 1
 #define FDES_STR 1024 /* BUZZ_SIZE, include/paramStructure.h:39 */
@@ -168,7 +173,9 @@ int fdes_plan_end_measurement(fdes_plan* plan, int k);
  * cannot form.  Not while an exit-wave output is wanted in a gang plan: then it runs one k after the other. */
 int fdes_plan_run_measurements(fdes_plan* plan, const int* ks, int n);
 /* Device pointer of the running intensity sum I (float2[m1*m2], .y = 0) so that the host
- * can reduce it across ranks (RCCL) between run_config and end_measurement. */
+ * can reduce it across ranks (RCCL) between run_config and end_measurement.  The call first issues what run_config has
+ * only queued (gangs) and folds the lanes' partial sums into I, stream-ordered: call fdes_plan_sync before another
+ * stream or the host touches the memory. */
 int fdes_plan_intensity_ptr(fdes_plan* plan, void** dev_ptr, size_t* bytes);
 /* D2D copy of I into (to_plan = 0) or from (to_plan = 1) a caller-owned DEVICE buffer of the size
  * fdes_plan_intensity_ptr reports; stream-ordered with the plan's work, synchronises before return.
@@ -179,8 +186,29 @@ int fdes_plan_copy_intensity(fdes_plan* plan, void* dev_buf, int to_plan);
 int fdes_plan_copy_intensity_real(fdes_plan* plan, void* dev_buf, int to_plan);
 /* dst.I += src.I (and dst's exit-wave sum += src's when both plans want it), device to device: the reduction of
  * src/crystalMaker.cu:347-365 for a measurement whose configurations ran on two plans.  Plans on different GPUs of
- * the process: one peer copy into a landing buffer on dst's GPU + one axpy kernel.  Synchronises dst. */
+ * the process: the intensity sum crosses as its real view (float[m1*m2]: its imaginary part is identically zero; 16 MiB
+ * at 2048^2), one peer copy into a landing buffer on dst's GPU + one add kernel.  Synchronises dst. */
 int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src);
+
+/* The same reduction as ONE collective over RCCL (ncclReduce(sum, float[m1*m2]) to the owner of the measurement),
+ * for hosts that run one context per GPU - threads of one process (fdes_build_measurements_multi with FDES_REDUCE=rccl) or
+ * one process per GPU.  librccl.so is loaded at run time on the first call (FDES_EUNSUPPORTED without it).
+ *   fdes_comm_unique_id   one rank makes the 128-byte id (ncclGetUniqueId) and hands it to the others by its own means;
+ *   fdes_comm_create      every rank, concurrently: ncclCommInitRank on the context's device; blocks until all have joined.
+ *                         One rank per GPU (RCCL refuses two ranks on one device).  Call it before the ranks create
+ *                         plans: it allocates device memory, which must not coincide with another thread's graph capture;
+ *   fdes_plan_reduce_intensity  EVERY rank of the communicator, for the SAME measurement, in the same order: the ranks'
+ *                         running intensity sums (lanes folded, gangs issued) are added onto `root`'s plan, whose sum then
+ *                         holds the total; the other ranks' sums are left as they were.  Stream-ordered behind the plan's
+ *                         work; synchronises.  The order of the additions is RCCL's (fixed for a given node and job shape,
+ *                         not the ascending-GPU order of fdes_plan_accumulate_from);
+ *   fdes_comm_destroy     after the context's plans are done with it, before fdes_destroy. */
+typedef struct fdes_comm fdes_comm;
+typedef struct { char bytes[128]; } fdes_comm_id; /* ncclUniqueId */
+int fdes_comm_unique_id(fdes_comm_id* id);
+int fdes_comm_create(fdes_ctx* ctx, int nranks, int rank, const fdes_comm_id* id, fdes_comm** comm);
+int fdes_comm_destroy(fdes_comm* comm);
+int fdes_plan_reduce_intensity(fdes_plan* plan, fdes_comm* comm, int root);
 /* Coherent exit-wave average (print_level > 1, src/crystalMaker.cu:347,370): switch the accumulation on before
  * fdes_plan_begin_measurement; fdes_plan_get_exitwave copies the sum of the current measurement, float[2*m1*m2]. */
 int fdes_plan_want_exitwave(fdes_plan* plan, int on);
@@ -218,15 +246,19 @@ int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
  *                neither transformed nor moved in the fused loop (exact: they hold zeros); 0: move everything
  *   "skip_empty" 1 (default): a slice that holds no atom has t = 1 exactly, so only its Fresnel step is run
  *                (2 passes instead of 5-6); 0: every slice goes through the full sequence like the reference
- *   "lanes"      1..8 configurations in flight at once in the fused slice loop (default 0: four up to 1024 x 1024 pixels,
- *                two above, never more than the job has configurations): run_config calls are
- *                dealt round-robin to lanes, partial intensity sums are folded in end_measurement
+ *   "lanes"      1..8 configurations (or gangs of them) in flight at once in the fused slice loop (default 0: three up to
+ *                1024 x 1024 pixels without gangs, two above and whenever the lanes run gangs, one for a small gang job;
+ *                never more than the job has configurations resp. gangs): run_config calls are dealt round-robin to
+ *                the lanes, partial intensity sums are folded in end_measurement (and by every call that hands out
+ *                or moves the sums: fdes_plan_intensity_ptr, fdes_plan_copy_intensity*, fdes_plan_accumulate_from)
  *   "gang"       configurations of one measurement (frozen-phonon configurations of one tilt / defocus) whose slice
  *                loops run in lockstep on a lane, every pass ONE launch with the configurations as grid z: fills the
  *                chip where one grid's rows cannot (up to 1024 x 1024).  -1 auto, 0 / 1 off, 2..16.  run_config then
  *                only queues; the work is issued when the gang is full or its results are asked for.
  *   "pass_threads"  0 auto; 256 or 512 threads x two rows per thread; 1: one row per thread, four rows per workgroup;
- *                64: one wave per row (2048- and 4096-point rows); 65: the same as a software pipeline
+ *                64: one wave per row (1024-, 2048- and 4096-point rows), four rows per workgroup; 128: the same with
+ *                eight rows per workgroup (2048-point rows); 65: 64 as a software pipeline.  (At 4096 points the band-limit
+ *                and propagator passes always run one wave per row with half-size LDS regions: two workgroups per CU.)
  *   "split"      -1 (default): a plan with one lane (single-image jobs; a plan never has more lanes than the job has
  *                configurations) and at least 2^20 pixels runs the potential / transmission passes of its slice loop on a second stream, one
  *                slice pair ahead of the wave's passes; 0 never, 1 always
@@ -234,7 +266,9 @@ int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
  *                or 8 (512^2 and below) slice pairs as one launch each, a batch ahead of the wave's passes;
  *                0 / 1 off, 2 ... 8 pairs per launch
  *   "pitch_pad"  -1 (default: 32 for 2048-point rows, 64 from 4096 on) elements of padding per row of the slice loop's grids
- *   "walk"       1 (default) .. 8: launch every pass in that many parts
+ *   "walk"       1 (default) .. 8: launch every pass in that many parts (an experiment of round 2; the multi-wave row kernels
+ *                implement it, so walk > 1 selects those instead of the one-wave-per-row kernels; the mixed-radix passes
+ *                ignore it)
  *   "deterministic"  1 (default): the deposit of the rocFFT slice loop and of the potential output adds the atoms in sorted
  *                order through LDS (bit-reproducible, like the fused loop); 0: global float atomics as the reference's
  *                squareAtoms_d (src/crystalMaker.cu:100-119)
@@ -263,6 +297,9 @@ int fdes_run_file(int gpu_index, int print_level, const char* input_name, const 
 
 int fdes_abi_version(void);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

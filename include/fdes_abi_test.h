@@ -12,6 +12,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden and an export list (fdes_amd/csrc/exports_*.txt): only what this header
+ * declares is a dynamic symbol. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* How many configurations have been asked which of their slices are empty (option "skip_empty": one D2H and one host
  * wait each); a specimen without empty slices stops being asked after eight configurations in a row (diagnostic). */
@@ -53,6 +58,9 @@ int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_
  *   "lanes_active"  n > 0: run_config deals only to the first n lanes from now on (0: all)
  *   "bench_band", "bench_alt", "bench_tall", "bench_pitch", "bench_serial"  shape fdes_bench_pass only */
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

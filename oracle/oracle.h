@@ -62,7 +62,9 @@ int oracle_get_threads(void);
     void oracle_wave_##S(const fdes_params* p, const fdes_atoms* a, int k, int j, uint32_t seed, \
                          int nslices, R* psi);                                                   \
     int oracle_build_measurements_##S(const fdes_params* p, const fdes_atoms* a, uint32_t seed,  \
-                                      R* image, R* potential, R* exitwave);
+                                      R* image, R* potential, R* exitwave);                      \
+    int oracle_measurement_##S(const fdes_params* p, const fdes_atoms* a, int k, uint32_t seed,  \
+                               R* image_k);
 
 ORACLE_DECL(float, f32)
 ORACLE_DECL(double, f64)

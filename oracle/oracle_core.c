@@ -711,6 +711,52 @@ void S(oracle_add_noise_and_mtf)(const fdes_params* p, int k, R* I, R* J)
 
 /* ============================== driver ================================================== */
 
+/* body of the k loop of buildMeasurements, src/crystalMaker.cu:324-373: the configurations j of measurement k, their
+ * average (alpha = 1 / count, :302-304) and the detector chain.  p: already sub-sliced. */
+static int one_measurement(const fdes_params* p, const fdes_atoms* a, int k, uint32_t seed, R* psi, R* I, R* ew, R* image_k, R* exitwave_k)
+{
+    const size_t m12 = (size_t)p->m1 * p->m2;
+    const int count = (p->frPh > 0) ? p->frPh : 1;
+    const R alpha = (R)(1.f / ((float)count));
+    int nprop = 0;
+    initial_values(I, m12, 0, 0);
+    initial_values(ew, m12, 0, 0);
+    for (int j = 0; j < count; j++) {
+        S(oracle_wave)(p, a, k, j, seed, p->m3, psi);
+        nprop += p->m3;
+        if (exitwave_k) caxpy(ew, psi, m12, alpha);
+        if (p->mode == 0) {
+            S(oracle_apply_lens)(p, k, psi);
+            intensity_values(psi, m12);
+            caxpy(I, psi, m12, alpha);
+        } else {
+            S(oracle_diffraction_pattern)(p, k, psi);
+            caxpy(I, psi, m12, alpha);
+        }
+    }
+    if (exitwave_k) memcpy(exitwave_k, ew, sizeof(R) * 2 * m12);
+    S(oracle_add_noise_and_mtf)(p, k, I, image_k);
+    return nprop;
+}
+
+/* ONE measurement k of the series (the same loop body; every random stream is keyed on (k, j), so the result is the
+ * k-th image of oracle_build_measurements): image_k n1*n2.  NOTE: dose noise (pD > 0) advances a per-run state across k
+ * in the full driver (src/crystalMaker.cu:295, 603) - use this entry for pD = 0 only. */
+int S(oracle_measurement)(const fdes_params* p0, const fdes_atoms* a, int k, uint32_t seed, R* image_k)
+{
+    fdes_params ps = *p0;
+    (void)oracle_sub_slices(&ps);
+    const size_t m12 = (size_t)ps.m1 * ps.m2;
+    R* psi = (R*)malloc(sizeof(R) * 2 * m12);
+    R* I = (R*)malloc(sizeof(R) * 2 * m12);
+    R* ew = (R*)malloc(sizeof(R) * 2 * m12);
+    const int n = one_measurement(&ps, a, k, seed, psi, I, ew, image_k, NULL);
+    free(psi); free(I); free(ew);
+    return n;
+}
+
+
+
 /* Wave of configuration (k, j) after `nslices` sub-slices: src/crystalMaker.cu:334-344.
  * `p` must already be sub-sliced. */
 void S(oracle_wave)(const fdes_params* p, const fdes_atoms* a, int k, int j, uint32_t seed, int nslices,
@@ -745,31 +791,12 @@ int S(oracle_build_measurements)(const fdes_params* p0, const fdes_atoms* a, uin
     int ratio = oracle_sub_slices(p);
     const size_t m12 = (size_t)p->m1 * p->m2;
     const size_t n12 = (size_t)p->n1 * p->n2;
-    int count = (p->frPh > 0) ? p->frPh : 1;
-    const R alpha = (R)(1.f / ((float)count));
     R* psi = (R*)malloc(sizeof(R) * 2 * m12);
     R* I = (R*)malloc(sizeof(R) * 2 * m12);
     R* ew = (R*)malloc(sizeof(R) * 2 * m12);
     int nprop = 0;
-    for (int k = 0; k < p->n3; k++) {
-        initial_values(I, m12, 0, 0);
-        initial_values(ew, m12, 0, 0);
-        for (int j = 0; j < count; j++) {
-            S(oracle_wave)(p, a, k, j, seed, p->m3, psi);
-            nprop += p->m3;
-            if (exitwave) caxpy(ew, psi, m12, alpha);
-            if (p->mode == 0) {
-                S(oracle_apply_lens)(p, k, psi);
-                intensity_values(psi, m12);
-                caxpy(I, psi, m12, alpha);
-            } else {
-                S(oracle_diffraction_pattern)(p, k, psi);
-                caxpy(I, psi, m12, alpha);
-            }
-        }
-        if (exitwave) memcpy(exitwave + 2 * m12 * (size_t)k, ew, sizeof(R) * 2 * m12);
-        S(oracle_add_noise_and_mtf)(p, k, I, image + n12 * (size_t)k);
-    }
+    for (int k = 0; k < p->n3; k++)
+        nprop += one_measurement(p, a, k, seed, psi, I, ew, image + n12 * (size_t)k, exitwave ? exitwave + 2 * m12 * (size_t)k : NULL);
     if (potential) {
         /* src/crystalMaker.cu:381-397: un-jittered, tilt-offset-only potential per ORIGINAL
          * slice.  (The reference leaves the buffer uninitialised when ratio==1, frPh==0 and the

@@ -4,9 +4,11 @@
 // stores and NO locking, so any pair of calls that the driver's barriers fail to order shows up as a data race.  The
 // result is also compared with the serial sum (partition + ownership logic).
 // Build + run: tests/test_host_cpu.py::test_multi_gpu_driver_under_thread_sanitizer
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -21,6 +23,26 @@ struct fdes_plan {
     bool want_ew = false;
     int cur_k = -1;
 };
+
+// stub communicator: the collective's own rendezvous is a real barrier (RCCL synchronises its ranks inside the call);
+// the data it moves is read and written with plain loads and stores like everything else here
+struct StubWorld {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 0, arrived = 0;
+    unsigned gen = 0;
+    std::vector<fdes_plan*> slot;
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned g = gen;
+        if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return g != gen; });
+    }
+};
+static StubWorld g_world;
+struct fdes_comm { int nranks, rank; };
+static int g_reduce_calls = 0; // (written by rank 0 only)
 
 static float contrib(int k, int j, size_t i) { return (float)((k * 131 + j * 17 + (int)(i % 97)) % 251) / 251.0f; }
 
@@ -58,6 +80,32 @@ int fdes_plan_accumulate_from(fdes_plan* d, fdes_plan* s)
     for (size_t i = 0; i < d->I.size(); i++) { d->I[i] += s->I[i]; if (d->want_ew) d->EW[i] += s->EW[i]; }
     return FDES_OK;
 }
+int fdes_comm_unique_id(fdes_comm_id* id) { std::memset(id, 7, sizeof *id); return FDES_OK; }
+int fdes_comm_create(fdes_ctx*, int nranks, int rank, const fdes_comm_id* id, fdes_comm** out)
+{
+    if (id->bytes[5] != 7) return FDES_EINVAL;
+    if (rank == 0) { g_world.n = nranks; g_world.slot.assign((size_t)nranks, nullptr); } // (the driver's barriers order this before any reduce)
+    *out = new fdes_comm{nranks, rank};
+    return FDES_OK;
+}
+int fdes_comm_destroy(fdes_comm* c) { delete c; return FDES_OK; }
+int fdes_plan_reduce_intensity(fdes_plan* pl, fdes_comm* c, int root)
+{
+    g_world.slot[(size_t)c->rank] = pl;
+    g_world.wait();
+    int rc = FDES_OK;
+    if (c->rank == root) {
+        if (c->rank == 0) g_reduce_calls++;
+        for (int r = 0; r < c->nranks; r++) {
+            const fdes_plan* s = g_world.slot[(size_t)r];
+            if (r == root) continue;
+            if (s->cur_k != pl->cur_k) rc = FDES_EINVAL; // every rank must hold the same measurement
+            for (size_t i = 0; i < pl->I.size(); i += 2) pl->I[i] += s->I[i]; // the real view only
+        }
+    }
+    g_world.wait();
+    return rc;
+}
 int fdes_plan_get_exitwave(fdes_plan* pl, float* ew) { std::memcpy(ew, pl->EW.data(), sizeof(float) * pl->EW.size()); return FDES_OK; }
 int fdes_plan_end_measurement(fdes_plan* pl, int k)
 {
@@ -86,8 +134,10 @@ int fdes_plan_potential(fdes_plan* pl, int lo, int hi, float* pot)
 }
 }
 
-static int run_case(int ngpu, int n3, int count, bool fail_one)
+static int run_case(int ngpu, int n3, int count, bool fail_one, bool rccl = false)
 {
+    if (rccl) setenv("FDES_REDUCE", "rccl", 1); else unsetenv("FDES_REDUCE");
+    const int reduce_calls_before = g_reduce_calls;
     fdes_params p;
     std::memset(&p, 0, sizeof p);
     p.n1 = 6; p.n2 = 5; p.m1 = 8; p.m2 = 8; p.n3 = n3; p.m3 = 7; p.frPh = count > 1 ? count : 0;
@@ -97,9 +147,10 @@ static int run_case(int ngpu, int n3, int count, bool fail_one)
     if (fail_one) dev[(size_t)(ngpu / 2)] = 99;
     const size_t m12 = 64, img = 30;
     std::vector<float> image(img * (size_t)n3, -1.f), pot(2 * m12 * 7, -1.f), ew(2 * m12 * (size_t)n3, -1.f);
-    const int rc = fdes_build_measurements_multi(ngpu, dev.data(), &p, &a, image.data(), pot.data(), ew.data());
+    const int rc = fdes_build_measurements_multi(ngpu, dev.data(), &p, &a, image.data(), pot.data(), rccl ? nullptr : ew.data());
     if (fail_one) return rc == FDES_OK ? 1 : 0; // must report the failure and must not hang
     if (rc != FDES_OK) return 1;
+    if (rccl && n3 == 1 && count >= ngpu && g_reduce_calls != reduce_calls_before + 1) return 1; // the collective path was taken
     const int cnt = count > 1 ? count : 1;
     const float w = 1.f / (float)cnt;
     int bad = 0;
@@ -109,7 +160,7 @@ static int run_case(int ngpu, int n3, int count, bool fail_one)
             for (int j = 0; j < cnt; j++) s += (double)w * contrib(k, j, 2 * (i % m12));
             if (std::abs((double)image[(size_t)k * img + i] - s) > 1e-5) bad++;
         }
-    for (int k = 0; k < n3; k++)
+    for (int k = 0; k < n3 && !rccl; k++)
         for (size_t i = 0; i < 2 * m12; i++) {
             double s = 0;
             for (int j = 0; j < cnt; j++) s += (double)w * contrib(k, j, i + 5);
@@ -131,6 +182,14 @@ int main()
         bad += b;
     }
     bad += run_case(4, 2, 4, true);
+    // FDES_REDUCE=rccl: measurements that span all GPUs go through ONE collective (stub communicator above), the others
+    // through the tree; a worker that fails must not leave its peers inside the collective
+    for (auto& c : cases) {
+        const int b = run_case(c[0], c[1], c[2], false, true);
+        std::printf("rccl: gpus %d measurements %d configurations %d: %s\n", c[0], c[1], c[2], b ? "MISMATCH" : "ok");
+        bad += b;
+    }
+    bad += run_case(4, 1, 8, true, true);
     std::printf(bad ? "FAILED\n" : "all ok\n");
     return bad ? 1 : 0;
 }

@@ -61,6 +61,8 @@ def lib():
         g("wave").argtypes = [_P(Params), _P(Atoms), C.c_int, C.c_int, u32, C.c_int, R]
         g("build_measurements").argtypes = [_P(Params), _P(Atoms), u32, R, R, R]
         g("build_measurements").restype = C.c_int
+        g("measurement").argtypes = [_P(Params), _P(Atoms), C.c_int, u32, R]
+        g("measurement").restype = C.c_int
     _lib = L
     # a 1-GPU box shares its host CPUs (16 per GPU): never let OpenMP spawn one thread per visible core
     L.oracle_set_threads(default_threads())
@@ -229,3 +231,15 @@ def build_measurements(hp, atoms, seed=1, prec="f32", want_potential=False, want
         hp.ptr, atoms.ptr, seed, _ptr(img, ct), _ptr(pot, ct) if want_potential else null,
         _ptr(ew, ct) if want_exitwave else null)
     return {"image": img, "potential": pot, "exitwave": ew, "nprop": n}
+
+
+def measurement(hp, atoms, k, seed=1, prec="f32"):
+    """Image k of the series alone (every random stream is keyed on (k, j); pD = 0 only). hp: consistent params BEFORE
+    sub-slicing. Returns image[n2, n1]."""
+    dt, ct, suf = _dt(prec)
+    c = hp.c
+    assert c.pD == 0.0
+    _threads_for(c.m1 * c.m2)
+    img = np.zeros((c.n2, c.n1), dt)
+    getattr(lib(), f"oracle_measurement_{suf}")(hp.ptr, atoms.ptr, int(k), seed, _ptr(img, ct))
+    return img

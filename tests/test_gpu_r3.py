@@ -344,9 +344,11 @@ def test_gang_of_configurations_does_not_change_a_bit(oracle, kw):
             r = eng.build_measurements(hp, at, want_exitwave=True)
             outs[label] = (r["image"], r["exitwave"])
             eng.close()
-        ref = oracle.build_measurements(hp, at, prec="f32")["image"] if kw["m"] <= 320 and skip == 0 else None
+        # the ungrouped result against the float32 oracle (same Philox streams) at every size (round 4: also 512^2 and
+        # 1024^2, at 5e-5; the gang results are bit-identical to it below)
+        ref = oracle.build_measurements(hp, at, prec="f32")["image"] if skip == 0 else None
         if ref is not None:
-            check(outs["off"][0], ref, None, 2e-4, f"gang off {kw}")
+            check(outs["off"][0], ref, None, 5e-5, f"gang off {kw}")
         for label, (img, ew) in outs.items():
             if skip == 0 and not label.endswith("lanes"):
                 assert np.array_equal(img, outs["off"][0]) and np.array_equal(ew, outs["off"][1]), (label, kw)
@@ -373,8 +375,8 @@ def test_gang_across_measurements_does_not_change_a_bit(oracle, kw):
             eng = fdes_amd.Engine(0, skip_empty=skip, **opts)
             outs[label] = eng.build_measurements(hp, at)["image"]
             eng.close()
-        if kw["m"] <= 320 and skip == 0 and not kw.get("pD"):
-            check(outs["off"], oracle.build_measurements(hp, at, prec="f32")["image"], None, 2e-4, f"series, gang off {kw}")
+        if skip == 0 and not kw.get("pD"):   # (round 4: at every size, 5e-5)
+            check(outs["off"], oracle.build_measurements(hp, at, prec="f32")["image"], None, 5e-5, f"series, gang off {kw}")
         for label, img in outs.items():
             if skip == 0:
                 assert np.array_equal(img, outs["off"]), (label, kw)

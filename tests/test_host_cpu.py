@@ -30,6 +30,39 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.fdes_abi_version() == 1
+    # ... and NOTHING else: the library is built hidden with an export list (fdes_amd/csrc/exports_product.txt for
+    # fdes_abi.h, exports_hooks.txt for fdes_abi_test.h; a TEST_HOOKS=0 build drops the second list)
+    out = subprocess.run(["nm", "-D", "--defined-only", abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    assert exported == declared, sorted(exported ^ declared)
+    csrc = os.path.join(ROOT, "fdes_amd", "csrc")
+    prod = set(open(os.path.join(csrc, "exports_product.txt")).read().split())
+    hooks = set(open(os.path.join(csrc, "exports_hooks.txt")).read().split())
+    h_prod = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fdes_abi.h")).read(), flags=re.S)
+    assert prod == set(re.findall(r"\b(fdes_[a-z0-9_]+|FDES)\s*\(", h_prod)) - {"fdes_abi_h_"}
+    assert prod | hooks == declared and not (prod & hooks)
+
+
+def test_export_list_without_test_hooks(tmp_path):
+    """`make TEST_HOOKS=0`: the version script of such a build lists the product entry points only."""
+    csrc = os.path.join(ROOT, "fdes_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, f"B={tmp_path}", "TEST_HOOKS=0", f"{tmp_path}/exports.map"], check=True)
+    names = set(re.findall(r"^([A-Za-z_0-9]+);", open(tmp_path / "exports.map").read(), flags=re.M))
+    assert names == set(open(os.path.join(csrc, "exports_product.txt")).read().split())
+    assert "fdes_bench_pass" not in names and "FDES" in names
+
+
+def test_library_builds_from_clean(tmp_path):
+    """Every object of the library from scratch into a scratch directory (the in-tree build reuses objects): all 13
+    translation units for gfx950, the link with the export list, and the result exports what the in-tree library does."""
+    csrc = os.path.join(ROOT, "fdes_amd", "csrc")
+    lib = tmp_path / "libFDES_SHARED_LIB.so"
+    r = subprocess.run(["make", "-s", "-j8", "-C", csrc, f"B={tmp_path}/build", f"LIB={lib}", str(lib)], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(os.listdir(tmp_path / "build")) == 14   # 13 objects + exports.map
+    out = subprocess.run(["nm", "-D", "--defined-only", str(lib)], capture_output=True, text=True, check=True).stdout
+    ref = subprocess.run(["nm", "-D", "--defined-only", abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert {l.split()[-1] for l in out.splitlines()} == {l.split()[-1] for l in ref.splitlines()}
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -801,6 +834,26 @@ def test_bench_deals_every_configuration_once_and_starts_its_own_ranks():
                          capture_output=True, text=True, timeout=120)
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["rank"] == 1 and lines[0]["timed_j"] == [1, 3]
+
+
+def test_bench_launcher_takes_the_other_ranks_down_when_one_dies():
+    """`python bench.py --gpus N` without a launcher: a rank that exits with an error before the rendezvous must not leave
+    the parent waiting on its siblings (they would block in init_process_group / a barrier): the parent polls all ranks,
+    terminates the rest on the first failure and returns that exit code; a deadline covers ranks that hang together."""
+    import time
+    env = dict(os.environ, FDES_BENCH_DRYRUN="fail:1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3, (out.returncode, out.stderr[-500:])
+    assert time.monotonic() - t0 < 60
+    # every rank hangs: the deadline ends the run with 124
+    env.update(FDES_BENCH_DRYRUN="fail:99", FDES_BENCH_DEADLINE_S="3")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 124, (out.returncode, out.stderr[-500:])
+    assert time.monotonic() - t0 < 60
 
 
 def test_pipelined_kernels_never_read_a_landing_register_early():
