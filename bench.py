@@ -62,8 +62,8 @@ def main():
         # launcher rehearsal of a rank that dies before the rendezvous: that rank exits 3 at once, the others would block
         if rank == int(os.environ["FDES_BENCH_DRYRUN"][5:]):
             sys.exit(3)
-        import time
-        time.sleep(300)
+        import time as _t   # (a plain `import time` here would make the name local to main() and break its closures)
+        _t.sleep(300)
         return
     if os.environ.get("FDES_BENCH_DRYRUN"):
         # launcher rehearsal without a GPU (tests/test_host_cpu.py): every rank reports what it WOULD run

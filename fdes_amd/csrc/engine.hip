@@ -122,7 +122,12 @@ struct fdes_plan {
     int64_t cfg_seen = 0, empty_queries = 0;
     unsigned rr = 0;                    // round-robin lane selector
     bool lanes_dirty = false;           // lanes hold partial sums not yet folded into lane 0
-    std::vector<int> seg_h;             // host copy of the (slice, species) segment table of the current configuration
+    std::vector<int> seg_h;             // per-slice occupancy of the current configuration as a monotone table [m3 * nZ + 1] (slice q is empty iff
+                                        // seg_h[(q + 1) nZ] == seg_h[q nZ]); empty: not asked
+    // "which slices are empty" is answered on a stream of its own (empty_query): the host never waits for a lane's slice loops
+    hipStream_t qs = nullptr;
+    int* slice_occ_d = nullptr;         // [gang][m3] occupancy flags
+    int* slice_occ_h = nullptr;         // pinned host copy
     int64_t slices_skipped = 0;
     float2 *A = nullptr, *B = nullptr, *C = nullptr, *C2 = nullptr, *E = nullptr, *F = nullptr, *PSIH = nullptr, *PT = nullptr;
     float* GT = nullptr;
@@ -311,6 +316,51 @@ int ensure_tilt(fdes_plan* pl, int k)
     return FDES_OK;
 }
 
+// Option skip_empty: which slices of the configurations (ks[g], js[g]), g < n, hold atoms -> pl->seg_h (slice q counts as
+// occupied when it is occupied in ANY of them: a gang skips a slice only when it is empty in every member).  Asked on the
+// plan's query stream from the constant tilt-offset coordinates (geom_slice_occupancy recomputes tilt, jitter and the
+// binning's slice test), so the one host wait per question covers a few microseconds of work of its own and NOT the slice
+// loops queued on the lane's stream (until round 3 the question read the binning's segment table behind them).
+// pl->gseg[g] receives member g's own table when n > 1.
+int empty_query(fdes_plan* pl, int n, const int* ks, const int* js)
+{
+    fdes_ctx* c = pl->ctx;
+    const int m3 = pl->p.m3, nZ = pl->nZ;
+    const int cap = pl->gang > 1 ? pl->gang : 1;
+    if (n > cap) return FDES_EINVAL;
+    if (!pl->qs) {
+        std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // allocations vs a capture in another thread
+        int least = 0, greatest = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(c, hipStreamCreateWithPriority(&pl->qs, hipStreamNonBlocking, greatest)); // a queue of its own, ahead of the lanes' kernels
+        RC(dmalloc(c, &pl->slice_occ_d, (size_t)cap * m3));
+        HIPCHK(c, hipHostMalloc((void**)&pl->slice_occ_h, sizeof(int) * (size_t)cap * m3, hipHostMallocDefault));
+    }
+    BinGeom g{pl->p.m1, pl->p.m2, m3, nZ, pl->p.d1, pl->p.d2, pl->p.d3};
+    for (int q = 0; q < n; q++)
+        HIPCHK(c, geom_slice_occupancy(pl->slice_occ_d + (size_t)q * m3, pl->xyzTO_d, pl->dwf_d, pl->nAt, g, pl->p.tiltspec[2 * ks[q]], pl->p.tiltspec[2 * ks[q] + 1],
+                                       pl->p.frPh > 0, owner_ctx(pl)->seed, ks[q], js[q], pl->qs));
+    HIPCHK(c, hipMemcpyAsync(pl->slice_occ_h, pl->slice_occ_d, sizeof(int) * (size_t)n * m3, hipMemcpyDeviceToHost, pl->qs));
+    HIPCHK(c, hipStreamSynchronize(pl->qs));
+    const size_t len = (size_t)m3 * nZ + 1;
+    auto table = [&](std::vector<int>& t, auto occupied) { // monotone, one step per occupied slice
+        t.assign(len, 0);
+        int cum = 0;
+        for (int q = 0; q < m3; q++) {
+            for (int z = 0; z < nZ; z++) t[(size_t)q * nZ + z] = cum;
+            cum += occupied(q) ? 1 : 0;
+        }
+        t[len - 1] = cum;
+    };
+    if (n > 1)
+        for (int q = 0; q < n; q++) {
+            if (pl->gseg.size() < (size_t)n) pl->gseg.resize((size_t)n);
+            table(pl->gseg[(size_t)q], [&](int s) { return pl->slice_occ_h[(size_t)q * m3 + s] != 0; });
+        }
+    table(pl->seg_h, [&](int s) { for (int q = 0; q < n; q++) if (pl->slice_occ_h[(size_t)q * m3 + s]) return true; return false; });
+    return FDES_OK;
+}
+
 // src/crystalMaker.cu:335-337 + the per-configuration (slice, species) binning
 int config_atoms(fdes_plan* pl, int k, int j, bool query = true, float* xyz = nullptr, AtomBins* bins_p = nullptr) // xyz / bins_p: a gang member's coordinates and binning buffers
 {
@@ -331,10 +381,9 @@ int config_atoms(fdes_plan* pl, int k, int j, bool query = true, float* xyz = nu
     if (ask && tp->dense_streak >= kDenseAfter && (tp->cfg_seen % kDenseRecheck) != 0) ask = false;
     tp->cfg_seen++;
     if (ask) {
-        // which slices hold atoms decides the launch sequence: one small D2H per configuration
-        pl->seg_h.resize((size_t)pl->p.m3 * pl->nZ + 1);
-        HIPCHK(c, hipMemcpyAsync(pl->seg_h.data(), bins.seg, sizeof(int) * pl->seg_h.size(), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // which slices hold atoms decides the launch sequence
+        const int kk = k, jj = j;
+        RC(empty_query(pl, 1, &kk, &jj));
         tp->empty_queries++;
         bool any_empty = false;
         for (int q = 0; q < pl->p.m3 && !any_empty; q++) any_empty = pl->seg_h[(size_t)(q + 1) * pl->nZ] == pl->seg_h[(size_t)q * pl->nZ];
@@ -1081,29 +1130,20 @@ int gang_flush(fdes_plan* pl)
             if (ask && tp->dense_streak >= kDenseAfter && (tp->cfg_seen % kDenseRecheck) >= n) ask = false;
             tp->cfg_seen += n;
             if (ask) {
-                const size_t len = (size_t)pl->p.m3 * pl->nZ + 1;
-                for (int g = 0; g < n; g++) {
-                    pl->gseg[(size_t)g].resize(len);
-                    HIPCHK(c, hipMemcpyAsync(pl->gseg[(size_t)g].data(), pl->gbins[(size_t)g].seg, sizeof(int) * len, hipMemcpyDeviceToHost, c->stream));
-                }
-                HIPCHK(c, hipStreamSynchronize(c->stream));
+                std::vector<int> qk((size_t)n), qj((size_t)n);
+                for (int g = 0; g < n; g++) { qk[(size_t)g] = pl->gq[(size_t)g].k; qj[(size_t)g] = pl->gq[(size_t)g].j; }
+                RC(empty_query(pl, n, qk.data(), qj.data())); // fills seg_h (occupied in ANY member) and, for n > 1, gseg[g]
                 tp->empty_queries++;
                 for (int g = 0; g < n; g++) {
+                    const std::vector<int>& t = n > 1 ? pl->gseg[(size_t)g] : pl->seg_h;
                     bool any_empty = false;
-                    for (int q = 0; q < pl->p.m3 && !any_empty; q++) any_empty = pl->gseg[(size_t)g][(size_t)(q + 1) * pl->nZ] == pl->gseg[(size_t)g][(size_t)q * pl->nZ];
+                    for (int q = 0; q < pl->p.m3 && !any_empty; q++) any_empty = t[(size_t)(q + 1) * pl->nZ] == t[(size_t)q * pl->nZ];
                     tp->dense_streak = any_empty ? 0 : tp->dense_streak + 1;
                 }
                 have_all = true;
             }
         }
-        // empty in every member <=> the SUM of the members' (monotone) segment tables does not move
-        if (have_all) {
-            pl->seg_h.assign(pl->gseg[0].size(), 0);
-            for (int g = 0; g < n; g++)
-                for (size_t i = 0; i < pl->seg_h.size(); i++) pl->seg_h[i] += pl->gseg[(size_t)g][i];
-        } else {
-            pl->seg_h.clear();
-        }
+        if (!have_all) pl->seg_h.clear();
         if (pl->ev_used == pl->evs.size()) {
             EvPair e{};
             HIPCHK(c, hipEventCreate(&e.a));
@@ -1421,6 +1461,9 @@ int fdes_plan_destroy(fdes_plan* pl)
     for (auto& e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : pl->probe) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (pl->peer_ev) (void)hipEventDestroy(pl->peer_ev);
+    if (pl->qs) { (void)hipStreamSynchronize(pl->qs); (void)hipStreamDestroy(pl->qs); }
+    if (pl->slice_occ_d) (void)hipFree(pl->slice_occ_d);
+    if (pl->slice_occ_h) (void)hipHostFree(pl->slice_occ_h);
     if (pl->split) {
         if (pl->vs) { (void)hipStreamSynchronize(pl->vs); (void)hipStreamDestroy(pl->vs); }
         for (hipEvent_t e : {pl->evE[0], pl->evE[1], pl->evP5[0], pl->evP5[1], pl->evFork, pl->evJoin}) if (e) (void)hipEventDestroy(e);

@@ -5,10 +5,12 @@
 // The kernels of fft_lds.hip / fft_wave.hip keep a row in registers and are unrolled per power-of-two length; here the
 // same pass structure (coalesced row loads -> [row FFT] -> point-wise operation -> [row FFT] -> natural or transposed
 // store, fft_lds.h) runs with the rows in LDS and the length as a run-time value, for any N = 2^a 3^b 5^c in
-// [256, 2048]: mixed-radix Stockham stages (radices 10, 8, 5, 4, 3, 2) between two LDS images of the row tile, one
+// [256, 4096]: mixed-radix Stockham stages (radices 10, 8, 5, 4, 3, 2) between two LDS images of the row tile, one
 // work item per butterfly, twiddles from a table of the N-th roots of unity (double-precision values rounded once;
-// every twiddle is ONE table entry), results in natural order after the last stage.  One workgroup = R rows (4 above
-// 512 points, 8 up to it: 32- resp. 64-byte segments in the transposed store).  The slice loop of the engine then runs
+// every twiddle is ONE table entry), results in natural order after the last stage.  One workgroup = R rows (8 up to
+// 512 points, 4 up to 2048, 2 beyond - two images of 2 x 4096 elements are 128 KiB, the twiddle table then stays in
+// global memory, i.e. in the caches: 64-, 32- resp. 16-byte segments in the transposed store; round 4: .qsc inputs give
+// m = 2 nx, src/rwQsc.cu:943-948, so nx = 1280 ... 2000 means 2560-, 3000-, 3072-, 3200-, 3600-, 4000-point rows).  The slice loop of the engine then runs
 // these sizes with the same 4.5 launches per slice as the power-of-two grids instead of rocFFT + point-wise kernels.
 #include "fft_lds.h"
 #include "geometry.h"
@@ -60,14 +62,17 @@ __host__ __device__ constexpr bool factorize(int n, GenFac& f)
     }
     return true;
 }
-__host__ __device__ constexpr int gen_rows(int n) { return n > 512 ? 4 : 8; }
+__host__ __device__ constexpr int gen_rows(int n) { return n > 2048 ? 2 : (n > 512 ? 4 : 8); }
+__host__ __device__ constexpr int gen_lrows(int rows) { return rows == 2 ? 1 : (rows == 4 ? 2 : 3); }
+// rows beyond 2048 points: the tile images fill the LDS, the twiddle table is read from global memory
+__host__ __device__ constexpr bool gen_tw_in_lds(int n) { return n <= 2048; }
 // the whole description of an n-point pass, as a compile-time constant for the specialised kernels (k_gpass<NC != 0>)
 __host__ __device__ constexpr GenFac make_fac(int n)
 {
     GenFac f;
     factorize(n, f);
     f.rows = gen_rows(n);
-    f.lrows = f.rows == 4 ? 2 : 3;
+    f.lrows = gen_lrows(f.rows);
     return f;
 }
 
@@ -245,7 +250,8 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
     const int tile = R * N;
     cf* cur = glds;
     cf* other = glds + tile;
-    cf* twl = glds + 2 * tile;
+    const bool tw_lds = gen_tw_in_lds(N);
+    const cf* twl = tw_lds ? glds + 2 * tile : reinterpret_cast<const cf*>(A.tw0);
     const int nvirt = (int)gridDim.x, vb = (int)blockIdx.x;
     int bg;
     {   // XCD-aware remap (fft_lds.hip): workgroups of one XCD own consecutive row groups
@@ -270,8 +276,11 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
     cf* const out0 = reinterpret_cast<cf*>(A.out) + zoff_out + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0);
     if constexpr (PRE != XF_NONE || POST != XF_NONE) {
-        const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
-        for (int i = tid; i < N; i += kGenThreads) twl[i] = tw[i];
+        if (tw_lds) {
+            const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
+            cf* twd = glds + 2 * tile;
+            for (int i = tid; i < N; i += kGenThreads) twd[i] = tw[i];
+        }
     }
     // this thread's elements: columns jt + tpr i of ONE row (the 512 / R threads of a row are consecutive: their loads of a
     // row are contiguous, and row and column need no arithmetic per element); EPT >= N / tpr = R N / 512
@@ -469,7 +478,7 @@ template <int NC, int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaun
     static std::atomic<unsigned long long> attr_set{0};
     auto kern = k_gpass<NC, EPT, PRE, MID, POST, ST>;
     // two images of the tile + the twiddle table
-    const size_t lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * 2 + (size_t)f.n) + 64;
+    const size_t lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * 2 + (gen_tw_in_lds(f.n) ? (size_t)f.n : (size_t)0)) + 64;
     int dev = 0;
     {
         hipError_t e = hipGetDevice(&dev);
@@ -530,7 +539,7 @@ template <int NC, int EPT> hipError_t gdispatch(int pre, int mid, int post, bool
 
 bool gen_pass_supported_len(int n)
 {
-    if (n < 256 || n > 2048) return false;
+    if (n < 256 || n > 4096) return false;
     if ((n & (n - 1)) == 0) return false; // powers of two have kernels of their own
     GenFac f;
     return factorize(n, f);
@@ -551,7 +560,7 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
     GenFac f;
     if (!gen_pass_supported_len(n) || !factorize(n, f)) return hipErrorInvalidValue;
     f.rows = gen_rows(n);
-    f.lrows = f.rows == 4 ? 2 : 3;
+    f.lrows = gen_lrows(f.rows);
     const int ept = (f.rows * n + kGenThreads - 1) / kGenThreads;
 #ifndef FDES_GEN_SPECIALISED
 #define FDES_GEN_SPECIALISED 1
@@ -566,6 +575,13 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
         if (n == 1280) return gdispatch<1280, 16>(pre, mid, post, st_t, a, f, st);
         if (n == 1600) return gdispatch<1600, 16>(pre, mid, post, st_t, a, f, st);
         if (n == 2000) return gdispatch<2000, 16>(pre, mid, post, st_t, a, f, st);
+        // m = 2 nx of a .qsc with nx = 1280, 1500, 1536, 1600, 1800, 2000 (src/rwQsc.cu:943-948): two-row tiles
+        if (n == 2560) return gdispatch<2560, 16>(pre, mid, post, st_t, a, f, st);
+        if (n == 3000) return gdispatch<3000, 16>(pre, mid, post, st_t, a, f, st);
+        if (n == 3072) return gdispatch<3072, 16>(pre, mid, post, st_t, a, f, st);
+        if (n == 3200) return gdispatch<3200, 16>(pre, mid, post, st_t, a, f, st);
+        if (n == 3600) return gdispatch<3600, 16>(pre, mid, post, st_t, a, f, st);
+        if (n == 4000) return gdispatch<4000, 16>(pre, mid, post, st_t, a, f, st);
     }
     if (ept <= 8) return gdispatch<0, 8>(pre, mid, post, st_t, a, f, st);
     if (ept <= 16) return gdispatch<0, 16>(pre, mid, post, st_t, a, f, st);

@@ -33,6 +33,10 @@ size_t geom_sort_temp_bytes(int nAt);
 hipError_t geom_bin_atoms(const float* xyz, const uint8_t* spec, const float* occ, int nAt, const BinGeom& g, AtomBins& b, bool with_rows,
                           hipStream_t st);
 // the same for the n <= 16 members of a gang in one launch each (member g: atoms [g nAt, (g + 1) nAt) of every array)
+// flags[s] = 1 for every slice s of configuration (k, j) that holds an atom the deposit will use, 0 elsewhere: tilt (t_0, t_1 of
+// measurement k), jitter and the binning's slice / border test recomputed from the constant tilt-offset coordinates (m3 ints)
+hipError_t geom_slice_occupancy(int* flags, const float* xyz0, const float* dwf, int nAt, const BinGeom& g, float t_0, float t_1, bool jitter,
+                                uint32_t seed, int k, int j, hipStream_t st);
 hipError_t geom_tilt_gang(float* out, const float* in, int nAt, int n, const float* t0, const float* t1, hipStream_t st);
 hipError_t geom_jitter_gang(float* out, const float* in, size_t in_stride, const float* dwf, int nAt, int n, uint32_t seed, const int* k,
                             const int* j, hipStream_t st);

@@ -45,6 +45,41 @@ __global__ void k_jitter(float* __restrict__ out, const float* __restrict__ in, 
     }
 }
 
+// Which slices of configuration (k, j) hold an atom that the deposit would use - WITHOUT the binning, from the plan's constant
+// tilt-offset coordinates: the tilt of measurement k (k_srot's arithmetic in tiltCoordinates' axis order: (x, z) by t_1, then
+// (y, z) by t_0), the frozen-phonon displacement of (k, j) (k_jitter's) and the slice / border test of k_atom_keys, fused per
+// atom, so that flags[slice] is set exactly where the binning of that configuration will find atoms.  The engine runs it on
+// a small stream of its own: the question "which slices are empty" (option skip_empty) then never waits for the slice loops
+// queued on the lane's stream.
+__global__ void k_slice_occupancy(const float* __restrict__ xyz0, const float* __restrict__ dwf, int nAt, BinGeom g, int rot1, float c1, float s1,
+                                  int rot0, float c0, float s0, int jitter, uint32_t seed, uint32_t k, uint32_t j, int* __restrict__ flags)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nAt; i += gridDim.x * blockDim.x) {
+        float x = xyz0[3 * i + 0], y = xyz0[3 * i + 1], z = xyz0[3 * i + 2];
+        if (rot1) {
+            const float cx = c1 * x, sz = s1 * z, cz = c1 * z, sx = s1 * x;
+            x = cx + sz;
+            z = cz - sx;
+        }
+        if (rot0) {
+            const float cy = c0 * y, sz = s0 * z, cz = c0 * z, sy = s0 * y;
+            y = cy + sz;
+            z = cz - sy;
+        }
+        if (jitter) {
+            const float sd = sqrtf(dwf[i]);
+            x = x + (normal(seed, 0u, k, j, (uint32_t)(3 * i + 0)) * 0.112539540f) * sd;
+            y = y + (normal(seed, 0u, k, j, (uint32_t)(3 * i + 1)) * 0.112539540f) * sd;
+            z = z + (normal(seed, 0u, k, j, (uint32_t)(3 * i + 2)) * 0.112539540f) * sd;
+        }
+        const float x1 = x / g.d1 + ((float)g.m1) * 0.5f - 0.5f;
+        const float x2 = y / g.d2 + ((float)g.m2) * 0.5f - 0.5f;
+        const float z3 = roundf(z / g.d3 + ((float)g.m3) * 0.5f - 0.5f);
+        const bool inside = (x1 > 1.f) && (x1 < (float)(g.m1 - 2)) && (x2 > 1.f) && (x2 < (float)(g.m2 - 2));
+        if (inside && z3 >= 0.f && z3 < (float)g.m3) flags[(int)z3] = 1; // (every writer stores the same value)
+    }
+}
+
 // key = ((i3 * nZ + species) * m2 + i2) for atoms that squareAtoms_d would deposit in some slice (i2 = nearest
 // row), else nq * m2 (sorted to the end).  Also records what the deposit needs.
 __global__ void k_atom_keys(const float* __restrict__ xyz, const uint8_t* __restrict__ spec, const float* __restrict__ occ, int nAt,
@@ -323,6 +358,18 @@ hipError_t geom_jitter(float* out, const float* in, const float* dwf, int nAt, u
     if (nAt <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_jitter, dim3(blocks_for(3 * nAt, 256, 2048)), dim3(256), 0, st, out, in, dwf, 3 * nAt, seed,
                        (uint32_t)k, (uint32_t)j);
+    return hipGetLastError();
+}
+
+hipError_t geom_slice_occupancy(int* flags, const float* xyz0, const float* dwf, int nAt, const BinGeom& g, float t_0, float t_1, bool jitter,
+                                uint32_t seed, int k, int j, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)g.m3, st);
+    if (e != hipSuccess || nAt <= 0) return e;
+    // tiltCoordinates (src/crystalMaker.cu:427-454): a rotation is skipped when |t| <= FLT_EPSILON; c = cos t, s = -sin t on the host
+    const int rot1 = fabsf(t_1) > FLT_EPSILON ? 1 : 0, rot0 = fabsf(t_0) > FLT_EPSILON ? 1 : 0;
+    hipLaunchKernelGGL(k_slice_occupancy, dim3(blocks_for(nAt, 256, 512)), dim3(256), 0, st, xyz0, dwf, nAt, g, rot1, cosf(t_1), -sinf(t_1), rot0,
+                       cosf(t_0), -sinf(t_0), jitter ? 1 : 0, seed, (uint32_t)k, (uint32_t)j, flags);
     return hipGetLastError();
 }
 

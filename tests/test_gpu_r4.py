@@ -66,3 +66,53 @@ def test_accumulate_from_moves_the_real_view():
         ea.close()
         eb.close()
     assert np.array_equal(imgs[0], imgs[1])
+
+
+@pytest.mark.parametrize("kw,opts", [(dict(m=256, m3=12, nz=2, nat=60, frPh=3, n3=3, tilt=True, zfrac=0.2, sub=2), dict(lanes=2, gang=0)),
+                                     (dict(m=256, m3=12, nz=2, nat=60, frPh=4, n3=2, tilt=True, zfrac=0.2), dict(lanes=1, gang=4)),
+                                     (dict(m=512, m3=9, nz=3, nat=40, n3=5, tilt=True, zfrac=0.15), dict()),
+                                     (dict(m=1024, m3=10, nz=1, nat=25, frPh=2, tilt=True, zfrac=0.1), dict(lanes=2, gang=0))])
+def test_empty_slice_question_on_its_own_stream(oracle, kw, opts):
+    """Option skip_empty: which slices of a configuration hold atoms is now answered on a query stream from the constant
+    coordinates (tilt of k, jitter of (k, j) and the binning's slice test recomputed: geom_slice_occupancy), not from the
+    binning's segment table behind the lane's queued slice loops.  Few atoms, tilts and jitter put atoms next to slice
+    boundaries: a slice wrongly taken for empty would lose its atoms.  Images with the short cut against the float32
+    oracle (same Philox streams) and against the full sequence on every slice; the question was really asked."""
+    hp, at = S.case_tiny(**kw)
+    fdes_amd.consistent(hp)
+    ref = oracle.build_measurements(hp, at, prec="f32")["image"]
+    out = {}
+    for skip in (1, 0):
+        eng = fdes_amd.Engine(0, skip_empty=skip, **opts)
+        out[skip] = eng.build_measurements(hp, at)["image"]
+        eng.close()
+    check(out[1], ref, None, 2e-5, f"empty-slice question {kw} {opts}")
+    assert relerr(out[1], out[0].astype(np.float64)) < 2e-5
+    eng = fdes_amd.Engine(0, skip_empty=1, **opts)
+    pl = eng.plan(hp, at)
+    pl.begin_measurement(0)
+    pl.run_config(0, 0, 1.0)
+    pl.sync()
+    assert pl.empty_queries() >= 1
+    pl.close()
+    eng.close()
+
+
+def test_qsc_sized_grids_beyond_2048_run_the_fused_loop(oracle):
+    """m = 2 nx for .qsc inputs (src/rwQsc.cu:943-948): nx = 1280 ... 2000 gives 2560-, 3000-, 3072-, 3200-, 3600-, 4000-point
+    grids, all 2^a 3^b 5^c; cuFFT serves them like any size (src/paramStructure.cu:676-679).  They now run the fused LDS
+    passes (mixed-radix rows, two-row tiles) instead of rocFFT + point-wise kernels: backend query, and a rectangular
+    2560 x 1280 image (two-row and four-row tiles in one plan) with frozen phonons through the whole driver against the float32 oracle."""
+    lib = fdes_amd.load_library()
+    for m in (2560, 3000, 3072, 3200, 3600, 4000):
+        assert lib.fdes_grid_backend(m, m, 0) == 2, m
+    assert lib.fdes_grid_backend(3000, 3000, 1) == 1 and lib.fdes_grid_backend(2058, 2058, 0) == 1   # 2058 = 2 * 3 * 7^3
+    hp, at = S.case_tiny(m=2560, m3=3, nz=2, nat=200, frPh=2, tilt=True, rect=True)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0)
+    pl = eng.plan(hp, at)
+    assert pl.fft_backend() == 2
+    pl.close()
+    out = eng.build_measurements(hp, at)["image"]
+    eng.close()
+    check(out, oracle.build_measurements(hp, at, prec="f32")["image"], None, 2e-5, f"fused loop on a {hp.c.m1} x {hp.c.m2} grid")
