@@ -343,7 +343,7 @@ def pmc_traffic(m):
     difference here returns (None, True) - stale - instead of a number that may belong to another build.  (None, False)
     for sizes that were not profiled."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
         for src, h in d.get("source_hash", {}).items():
             if h != _blob_hash(os.path.join(ROOT, src)):
                 return None, True

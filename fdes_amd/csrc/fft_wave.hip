@@ -510,7 +510,7 @@ __device__ __forceinline__ int live_cols(int i2, int md2)
 template <int N, int MID, bool PIPE> constexpr bool whalfx()
 {
     return ((N == 2048 && !PIPE && (((FDES_W_HALFX & 1) && MID == MID_MASK) || ((FDES_W_HALFX & 2) && MID == MID_PTAB))) ||
-            (N == 4096 && !PIPE && (((FDES_W_HALFX & 4) && MID == MID_MASK) || ((FDES_W_HALFX & 8) && MID == MID_PTAB))));
+            (N == 4096 && !PIPE && (((FDES_W_HALFX & 4) && MID == MID_MASK) || ((FDES_W_HALFX & 8) && MID == MID_PTAB) || ((FDES_W_HALFX & 16) && MID == MID_GTAB))));
 }
 template <int N, int MID, bool PIPE> constexpr size_t wlds_bytes()
 {
@@ -580,20 +580,21 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     constexpr bool ACC = PIPE && FDES_W_ACC_PREFETCH && !WALK; // look-ahead operands land in the accumulation registers
     cf an[LOADS_ROW ? P : 1];
     cf bn[PRE_B ? P : 1];
-    float gn[(MID == MID_GTAB) ? P : 1];
+    constexpr bool G_LATE = (MID == MID_GTAB) && HX && N > 2048; // the filter values are read at the point of use: 64 registers fewer across the first transform
+    float gn[(MID == MID_GTAB && !G_LATE) ? P : 1];
     auto request = [&](int row0_) {
         const size_t rb = (size_t)(row0_ + w) * pin; // wave-uniform
         if constexpr (ACC) {
             if constexpr (LOADS_ROW) wload_row_acc<N>(an, reinterpret_cast<const cf*>(A.in0) + rb, t, (A.skip_dead_loads & 1) != 0);
             if constexpr (PRE_B) wload_row_acc<N>(bn, reinterpret_cast<const cf*>(A.in1) + rb, t, (A.skip_dead_loads & 2) != 0);
-            if constexpr (MID == MID_GTAB) {
+            if constexpr (MID == MID_GTAB && !G_LATE) {
 #pragma unroll
                 for (int l = 0; l < P; l++) acc_load32(gn[l], (unsigned)(t + 64 * l) * 4u, A.gtab + rb);
             }
         } else {
             if constexpr (LOADS_ROW) wload_row<N>(an, reinterpret_cast<const cf*>(A.in0) + rb + zoff_in, t, (A.skip_dead_loads & 1) != 0);
             if constexpr (PRE_B) wload_row<N>(bn, reinterpret_cast<const cf*>(A.in1) + rb + zoff_in1, t, (A.skip_dead_loads & 2) != 0);
-            if constexpr (MID == MID_GTAB) {
+            if constexpr (MID == MID_GTAB && !G_LATE) {
 #pragma unroll
                 for (int l = 0; l < P; l++) gn[l] = A.gtab[rb + t + 64 * l];
             }
@@ -610,7 +611,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
 #pragma unroll
             for (int l = 0; l < P; l++) bn[l] = cf{0.f, 0.f};
         }
-        if constexpr (MID == MID_GTAB) {
+        if constexpr (MID == MID_GTAB && !G_LATE) {
 #pragma unroll
             for (int l = 0; l < P; l++) gn[l] = 0.f;
         }
@@ -638,14 +639,14 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
 
     cf a[P];
     cf b[(MID == MID_MULPSI) ? P : 1]; // second operand of the product
-    float gvv[(MID == MID_GTAB) ? P : 1];
+    float gvv[(MID == MID_GTAB && !G_LATE) ? P : 1];
     float vim[(MID == MID_EXPIV_PAIR) ? P : 1];
     if constexpr (ACC) {
         // the look-ahead of this group has landed: waited for before the loop resp. at the end of the previous iteration,
         // i.e. before any copy the compiler may place on the loop's back edge
         if constexpr (LOADS_ROW) wtake_row<N>(a, an, t, (A.skip_dead_loads & 1) != 0);
         if constexpr (PRE_B) wtake_row<N>(b, bn, t, (A.skip_dead_loads & 2) != 0);
-        if constexpr (MID == MID_GTAB) {
+        if constexpr (MID == MID_GTAB && !G_LATE) {
 #pragma unroll
             for (int l = 0; l < P; l++) gvv[l] = acc_read(gn[l]);
         }
@@ -658,7 +659,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
 #pragma unroll
         for (int l = 0; l < P; l++) b[l] = bn[l];
     }
-    if constexpr (MID == MID_GTAB) {
+    if constexpr (MID == MID_GTAB && !G_LATE) {
 #pragma unroll
         for (int l = 0; l < P; l++) gvv[l] = gn[l];
     }
@@ -778,6 +779,9 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
         } else if constexpr (MID == MID_SCALE) {
 #pragma unroll
             for (int l = 0; l < P; l++) a[l] = cf{a[l].x * A.scale, a[l].y * A.scale};
+        } else if constexpr (MID == MID_GTAB && G_LATE) {
+#pragma unroll
+            for (int l = 0; l < P; l++) { const float gv = gtab[t + 64 * l]; a[l] = cf{a[l].x * gv, a[l].y * gv}; }
         } else if constexpr (MID == MID_GTAB) {
 #pragma unroll
             for (int l = 0; l < P; l++) a[l] = cf{a[l].x * gvv[l], a[l].y * gvv[l]};
@@ -969,8 +973,9 @@ bool wave_pass_supported_len(int n) { return n == 1024 || n == 2048 || n == 4096
 // 4096 points (half-size LDS regions, above)
 bool wave_pass_preferred(int n, int pre, int mid, int post, bool st_t)
 {
-    return n == 4096 && st_t && pre == XF_FWD && post == XF_INV && whalfx<4096, MID_MASK, false>() && whalfx<4096, MID_PTAB, false>() &&
-           (mid == MID_MASK || mid == MID_PTAB);
+    if (!(n == 4096 && st_t && pre == XF_FWD && post == XF_INV)) return false;
+    return (mid == MID_MASK && whalfx<4096, MID_MASK, false>()) || (mid == MID_PTAB && whalfx<4096, MID_PTAB, false>()) ||
+           (mid == MID_GTAB && whalfx<4096, MID_GTAB, false>());
 }
 
 hipError_t wave_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs& a_in, hipStream_t st)
