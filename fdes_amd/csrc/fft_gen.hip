@@ -62,7 +62,18 @@ __host__ __device__ constexpr bool factorize(int n, GenFac& f)
     }
     return true;
 }
-__host__ __device__ constexpr int gen_rows(int n) { return n > 2048 ? 2 : (n > 512 ? 4 : 8); }
+#ifndef FDES_GEN_ROWS4
+#define FDES_GEN_ROWS4 0 // experiment: four-row tiles (32-byte segments, one workgroup per CU) for the specialised lengths beyond 2048 points
+#endif
+#ifndef FDES_GEN_TW_LDS_LIMIT
+#define FDES_GEN_TW_LDS_LIMIT 81920 // one-image kernels keep the twiddle table in LDS while tile + table fit this many bytes
+#endif
+__host__ __device__ constexpr bool gen_specialised(int n)
+{
+    return n == 320 || n == 800 || n == 1000 || n == 400 || n == 500 || n == 640 || n == 1280 || n == 1600 || n == 2000 || n == 2560 || n == 3000 ||
+           n == 3072 || n == 3200 || n == 3600 || n == 4000;
+}
+__host__ __device__ constexpr int gen_rows(int n) { return n > 2048 ? ((FDES_GEN_ROWS4 && gen_specialised(n)) ? 4 : 2) : (n > 512 ? 4 : 8); }
 __host__ __device__ constexpr int gen_lrows(int rows) { return rows == 2 ? 1 : (rows == 4 ? 2 : 3); }
 // rows beyond 2048 points: the tile images fill the LDS, the twiddle table is read from global memory
 __host__ __device__ constexpr bool gen_tw_in_lds(int n) { return n <= 2048; }
@@ -195,13 +206,93 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
     }
 }
 
+// twiddle table of a pass: 1 = all N roots in LDS, 2 = the first N / 2 in LDS (one-image kernels whose tile + full table
+// would not fit twice on a CU: 3600 and 4000 points; measured 1.48 k -> see profiles/r04_mixed_radix_beyond_2048.txt; even N
+// only), 0 = read from global memory
+__host__ __device__ constexpr int gen_tw_mode(int n, int rows, bool one_image)
+{
+    if (!one_image) return n <= 2048 ? 1 : 0;
+    if (sizeof(float) * 2 * ((size_t)rows * n + n) + 64 <= (size_t)FDES_GEN_TW_LDS_LIMIT) return 1;
+    if (n % 2 == 0 && sizeof(float) * 2 * ((size_t)rows * n + n / 2) + 64 <= (size_t)FDES_GEN_TW_LDS_LIMIT) return 2;
+    return 0;
+}
+
+// The same stage IN PLACE (compile-time lengths beyond 1024 points, round 4): a thread first takes the inputs of ALL its
+// butterflies into registers (at most NBT = ceil(n / 2 / tpr) butterflies of radix >= 2: a few dozen registers), the row's
+// threads meet, then it transforms and writes them back to the SAME image.  One image instead of two halves the LDS of a
+// workgroup: two workgroups per CU where the two-image form admits one (1280 ... 4000-point rows), at the price of a second
+// barrier per stage.
+template <int RX, int NBT, bool HALF_TW>
+__device__ __forceinline__ void gen_stage_inplace(cf* __restrict__ img, const cf* __restrict__ twl, const int N, const int nb, const int Ns,
+                                                  const int tws, const unsigned magic, const float s, const int row, const int jt, const int tpr)
+{
+    cf* __restrict__ rowp = img + row * N;
+    cf x[NBT][10];
+#pragma unroll
+    for (int b = 0; b < NBT; b++) {
+        const int j = jt + b * tpr;
+        if (j < nb) {
+#pragma unroll
+            for (int i = 0; i < RX; i++) x[b][i] = rowp[j + i * nb];
+        }
+    }
+    __syncthreads(); // every input of the stage has been read
+#pragma unroll
+    for (int b = 0; b < NBT; b++) {
+        const int j = jt + b * tpr;
+        if (j < nb) {
+            const int k = (Ns > 1) ? j - (int)__umulhi((unsigned)j, magic) * Ns : 0;
+            if (Ns > 1) {
+                const int dk = k * tws;
+#pragma unroll
+                for (int i = 1; i < RX; i++) {
+                    if constexpr (HALF_TW) { // the table holds W_N^m for m < N / 2 only: W_N^(m + N/2) = -W_N^m
+                        const int m = i * dk, h = N >> 1;
+                        const cf w = twl[m >= h ? m - h : m];
+                        x[b][i] = wmul_s(x[b][i], m >= h ? -w : w, s);
+                    } else {
+                        x[b][i] = wmul_s(x[b][i], twl[i * dk], s);
+                    }
+                }
+            }
+            if constexpr (RX == 2) dft2(x[b]);
+            if constexpr (RX == 3) dft3(x[b], s);
+            if constexpr (RX == 4) dft4(x[b], s);
+            if constexpr (RX == 5) dft5(x[b], s);
+            if constexpr (RX == 8) dft8(x[b], s);
+            if constexpr (RX == 10) dft10(x[b], s);
+            cf* __restrict__ out = rowp + (j - k) * RX + k;
+#pragma unroll
+            for (int i = 0; i < RX; i++) out[i * Ns] = x[b][i];
+        }
+    }
+}
+// all stages of an NC-point row in place; the recursion makes every stage's radix and butterfly count per thread constants
+template <int NC, int Q> __device__ __forceinline__ void gen_inplace_stages(cf* __restrict__ img, const cf* __restrict__ twl, const float s, const int row, const int jt)
+{
+    constexpr GenFac F = make_fac(NC);
+    if constexpr (Q < F.nf) {
+        constexpr int RX = F.radix[Q], nb = F.nbf[Q], tpr = kGenThreads >> F.lrows, NBT = (nb + tpr - 1) / tpr;
+        gen_stage_inplace<RX, NBT, gen_tw_mode(NC, F.rows, true) == 2>(img, twl, F.n, nb, F.ns[Q], F.tws[Q], F.magic[Q], s, row, jt, tpr);
+        __syncthreads();
+        gen_inplace_stages<NC, Q + 1>(img, twl, s, row, jt);
+    }
+}
+// one image for the compile-time lengths beyond 1024 points (see gen_stage_inplace)
+__host__ __device__ constexpr bool gen_one_image(int nc) { return nc > 1024; }
+// twiddle table in LDS while the workgroup then still fits twice on a CU (80 KiB), else read from global memory
+
 // row FFTs of the whole tile; on return `cur` points at the image that holds the result (natural order)
 // (CT: F is a compile-time constant - the stage loop is unrolled, every stage's radix, counts and index arithmetic fold)
-template <bool CT>
+template <bool CT, bool ONE = false, int NCI = 320>
 __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restrict__ twl, const GenFac& F, const bool inverse)
 {
     const float s = inverse ? -1.f : 1.f;
     const int tpr = kGenThreads >> F.lrows, row = (int)threadIdx.x / tpr, jt = (int)threadIdx.x - row * tpr; // tpr is a power of two
+    if constexpr (ONE) {
+        gen_inplace_stages<NCI, 0>(cur, twl, s, row, jt);
+        return;
+    }
     auto stage = [&](const int q) {
         const int rx = F.radix[q];
         switch (rx) {
@@ -240,7 +331,7 @@ __device__ __forceinline__ bool gen_outside(int i1, int i2, float md) { return (
 // (the reference's shipped grids 320, 800, 1000: the generic kernel spends ten times the vector instructions per point
 // of the power-of-two kernels on stage bookkeeping and index arithmetic)
 template <int NC, int EPT, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 2)) void k_gpass(PassArgs A, GenFac Frt) // EPT <= 8 (rows up to 1024 points): two workgroups per CU (the species loop of MID_GTABN needs more than 128 registers)
+__global__ __launch_bounds__(kGenThreads, (((EPT <= 8 || (NC != 0 && gen_one_image(NC))) && MID != MID_GTABN) ? 4 : 2)) void k_gpass(PassArgs A, GenFac Frt) // EPT <= 8 (rows up to 1024 points): two workgroups per CU (the species loop of MID_GTABN needs more than 128 registers)
 {
     constexpr bool CT = NC != 0;
     constexpr GenFac FC = make_fac(CT ? NC : 320);
@@ -248,10 +339,13 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
     extern __shared__ cf glds[];
     const int N = F.n, R = F.rows, tid = threadIdx.x;
     const int tile = R * N;
+    constexpr bool ONE = CT && gen_one_image(NC);
     cf* cur = glds;
-    cf* other = glds + tile;
-    const bool tw_lds = gen_tw_in_lds(N);
-    const cf* twl = tw_lds ? glds + 2 * tile : reinterpret_cast<const cf*>(A.tw0);
+    cf* other = ONE ? glds : glds + tile;
+    const int nimg = ONE ? 1 : 2;
+    const int tw_mode = CT ? gen_tw_mode(FC.n, FC.rows, ONE) : (gen_tw_in_lds(N) ? 1 : 0);
+    const bool tw_lds = tw_mode != 0;
+    const cf* twl = tw_lds ? glds + nimg * tile : reinterpret_cast<const cf*>(A.tw0);
     const int nvirt = (int)gridDim.x, vb = (int)blockIdx.x;
     int bg;
     {   // XCD-aware remap (fft_lds.hip): workgroups of one XCD own consecutive row groups
@@ -278,8 +372,8 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
     if constexpr (PRE != XF_NONE || POST != XF_NONE) {
         if (tw_lds) {
             const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
-            cf* twd = glds + 2 * tile;
-            for (int i = tid; i < N; i += kGenThreads) twd[i] = tw[i];
+            cf* twd = glds + nimg * tile;
+            for (int i = tid; i < (tw_mode == 2 ? N / 2 : N); i += kGenThreads) twd[i] = tw[i];
         }
     }
     // this thread's elements: columns jt + tpr i of ONE row (the 512 / R threads of a row are consecutive: their loads of a
@@ -313,7 +407,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
             const size_t zo = (size_t)z * A.species_stride;
             load_tile(in0 + zo, cur, false);
             __syncthreads();
-            if constexpr (PRE != XF_NONE) gen_fft<CT>(cur, other, twl, F, PRE == XF_INV);
+            if constexpr (PRE != XF_NONE) gen_fft<CT, ONE, (CT ? NC : 320)>(cur, other, twl, F, PRE == XF_INV);
 #pragma unroll
             for (int i = 0; i < EPT; i++)
                 if (valid(i)) {
@@ -395,7 +489,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
                 }
             load_tile(in1, cur, (A.skip_dead_loads & 2) != 0);
             __syncthreads();
-            if constexpr (PRE != XF_NONE) gen_fft<CT>(cur, other, twl, F, PRE == XF_INV);
+            if constexpr (PRE != XF_NONE) gen_fft<CT, ONE, (CT ? NC : 320)>(cur, other, twl, F, PRE == XF_INV);
 #pragma unroll
             for (int i = 0; i < EPT; i++)
                 if (valid(i)) keep_b[i] = cur[er[i] * N + ec[i]];
@@ -405,7 +499,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
                 if (valid(i)) cur[er[i] * N + ec[i]] = areg[i];
         }
         __syncthreads();
-        if constexpr (PRE != XF_NONE) gen_fft<CT>(cur, other, twl, F, PRE == XF_INV);
+        if constexpr (PRE != XF_NONE) gen_fft<CT, ONE, (CT ? NC : 320)>(cur, other, twl, F, PRE == XF_INV);
         // ---- point-wise operation on this thread's elements
         const float md = (float)A.mindim;
 #pragma unroll
@@ -450,7 +544,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
             }
         }
     };
-    if constexpr (POST != XF_NONE) gen_fft<CT>(cur, other, twl, F, POST == XF_INV);
+    if constexpr (POST != XF_NONE) gen_fft<CT, ONE, (CT ? NC : 320)>(cur, other, twl, F, POST == XF_INV);
     store_tile(out0);
     if constexpr (MID == MID_EXPIV_PAIR) {
         __syncthreads();
@@ -465,7 +559,7 @@ __global__ __launch_bounds__(kGenThreads, ((EPT <= 8 && MID != MID_GTABN) ? 4 : 
                 cur[er[i] * N + ec[i]] = cf{e * cs, e * sn};
             }
         __syncthreads();
-        if constexpr (POST != XF_NONE) gen_fft<CT>(cur, other, twl, F, POST == XF_INV);
+        if constexpr (POST != XF_NONE) gen_fft<CT, ONE, (CT ? NC : 320)>(cur, other, twl, F, POST == XF_INV);
         store_tile(reinterpret_cast<cf*>(A.out2) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_out2 : (size_t)0));
     }
 }
@@ -478,7 +572,9 @@ template <int NC, int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaun
     static std::atomic<unsigned long long> attr_set{0};
     auto kern = k_gpass<NC, EPT, PRE, MID, POST, ST>;
     // two images of the tile + the twiddle table
-    const size_t lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * 2 + (gen_tw_in_lds(f.n) ? (size_t)f.n : (size_t)0)) + 64;
+    constexpr bool ONE = NC != 0 && gen_one_image(NC);
+    const int tw_mode = NC != 0 ? gen_tw_mode(f.n, f.rows, ONE) : (gen_tw_in_lds(f.n) ? 1 : 0);
+    const size_t lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * (ONE ? 1 : 2) + (tw_mode == 1 ? (size_t)f.n : (tw_mode == 2 ? (size_t)f.n / 2 : (size_t)0))) + 64;
     int dev = 0;
     {
         hipError_t e = hipGetDevice(&dev);
@@ -576,12 +672,12 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
         if (n == 1600) return gdispatch<1600, 16>(pre, mid, post, st_t, a, f, st);
         if (n == 2000) return gdispatch<2000, 16>(pre, mid, post, st_t, a, f, st);
         // m = 2 nx of a .qsc with nx = 1280, 1500, 1536, 1600, 1800, 2000 (src/rwQsc.cu:943-948): two-row tiles
-        if (n == 2560) return gdispatch<2560, 16>(pre, mid, post, st_t, a, f, st);
-        if (n == 3000) return gdispatch<3000, 16>(pre, mid, post, st_t, a, f, st);
-        if (n == 3072) return gdispatch<3072, 16>(pre, mid, post, st_t, a, f, st);
-        if (n == 3200) return gdispatch<3200, 16>(pre, mid, post, st_t, a, f, st);
-        if (n == 3600) return gdispatch<3600, 16>(pre, mid, post, st_t, a, f, st);
-        if (n == 4000) return gdispatch<4000, 16>(pre, mid, post, st_t, a, f, st);
+        if (n == 2560) return gdispatch<2560, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
+        if (n == 3000) return gdispatch<3000, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
+        if (n == 3072) return gdispatch<3072, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
+        if (n == 3200) return gdispatch<3200, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
+        if (n == 3600) return gdispatch<3600, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
+        if (n == 4000) return gdispatch<4000, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
     }
     if (ept <= 8) return gdispatch<0, 8>(pre, mid, post, st_t, a, f, st);
     if (ept <= 16) return gdispatch<0, 16>(pre, mid, post, st_t, a, f, st);

@@ -145,7 +145,7 @@ def test_wave_passes_equal_lanes_graph_and_empty_slices(oracle, threads):
 # ------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("shape", [(320, 320), (800, 800), (1000, 1000), (1000, 512), (640, 960), (1280, 1500), (2000, 1920),
-                                   (3000, 3000), (2560, 3072), (3600, 4000), (3200, 4096), (2048, 2560)])   # (round 4: lengths beyond 2048)
+                                   (3000, 3000), (2560, 3072), (3600, 4000), (3200, 4096), (2048, 2560), (2304, 2700), (1600, 1280)])   # (round 4: lengths beyond 2048; 2304 x 2700: run-time-length kernels there)
 def test_mixed_radix_fft_against_numpy(engine, shape):
     """Row FFTs of length 2^a 3^b 5^c (Stockham stages of radix 10, 8, 5, 4, 3, 2 in LDS) as a 2-D transform against
     numpy, also paired with a power-of-two length (cufftPlan2d serves any size, src/paramStructure.cu:676-679)."""
