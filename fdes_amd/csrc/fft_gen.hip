@@ -4,8 +4,8 @@
 // 1000-point grids (bin/dataFDES.cnf; bin/test.qsc: m = 2 nx, src/rwQsc.cu:943-948; ExampleSpecimens/Si_001_11k_cnf).
 // The kernels of fft_lds.hip / fft_wave.hip keep a row in registers and are unrolled per power-of-two length; here the
 // same pass structure (coalesced row loads -> [row FFT] -> point-wise operation -> [row FFT] -> natural or transposed
-// store, fft_lds.h) runs with the rows in LDS and the length as a run-time value, for any N = 2^a 3^b 5^c in
-// [256, 4096]: mixed-radix Stockham stages (radices 10, 8, 5, 4, 3, 2) between two LDS images of the row tile, one
+// store, fft_lds.h) runs with the rows in LDS and the length as a run-time value, for any N = 2^a 3^b 5^c 7^d in
+// [256, 4096]: mixed-radix Stockham stages (radices 10, 8, 7, 5, 4, 3, 2) between two LDS images of the row tile, one
 // work item per butterfly, twiddles from a table of the N-th roots of unity (double-precision values rounded once;
 // every twiddle is ONE table entry), results in natural order after the last stage.  One workgroup = R rows (8 up to
 // 512 points, 4 up to 2048, 2 beyond - two images of 2 x 4096 elements are 128 KiB, the twiddle table then stays in
@@ -37,15 +37,15 @@ struct GenFac {
     unsigned magic[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
-// factors and stage tables of an n-point row; false if n has a prime factor above 5 or more than 8 stages
+// factors and stage tables of an n-point row; false if n has a prime factor above 7 or more than 8 stages
 __host__ __device__ constexpr bool factorize(int n, GenFac& f)
 {
     f.n = n;
     f.nf = 0;
     int m = n;
     // large radices first: fewer stages (each stage is one trip of the tile through LDS)
-    const int cand[6] = {10, 8, 5, 4, 3, 2};
-    for (int ci = 0; ci < 6; ci++)
+    const int cand[7] = {10, 8, 7, 5, 4, 3, 2};
+    for (int ci = 0; ci < 7; ci++)
         while (m % cand[ci] == 0 && m > 1) {
             if (f.nf == 8) return false;
             f.radix[f.nf++] = cand[ci];
@@ -136,6 +136,25 @@ __device__ __forceinline__ void dft5_(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4, fl
     x3 = m2 - n2;
 }
 __device__ __forceinline__ void dft5(cf (&x)[10], float s) { dft5_(x[0], x[1], x[2], x[3], x[4], s); }
+// radix 7 (round 4: 7-smooth lengths such as 448, 896, 1400, 1792, 2016, 3584): the six non-trivial outputs from the three
+// symmetric sums a_j = x_j + x_(7-j) and differences b_j = x_j - x_(7-j), X_k = x_0 + sum_j a_j cos(2 pi j k / 7) -/+ i sum_j b_j sin(2 pi j k / 7)
+__device__ __forceinline__ void dft7(cf (&x)[10], float s)
+{
+    constexpr float c1 = 0.623489801858733530f, c2 = -0.222520933956314404f, c3 = -0.900968867902419126f; // cos(2 pi j / 7)
+    constexpr float s1 = 0.781831482468029809f, s2 = 0.974927912181823607f, s3 = 0.433883739117558120f;  // sin(2 pi j / 7)
+    const cf a1 = x[1] + x[6], a2 = x[2] + x[5], a3 = x[3] + x[4];
+    const cf b1 = x[1] - x[6], b2 = x[2] - x[5], b3 = x[3] - x[4];
+    const cf m1 = x[0] + a1 * c1 + a2 * c2 + a3 * c3; // k = 1, 6: cos(2 pi j k / 7) = c1, c2, c3
+    const cf m2 = x[0] + a1 * c2 + a2 * c3 + a3 * c1; // k = 2, 5: c2, c4 = c3, c6 = c1
+    const cf m3 = x[0] + a1 * c3 + a2 * c1 + a3 * c2; // k = 3, 4: c3, c6 = c1, c9 = c2
+    const cf n1 = mi_s(b1 * s1 + b2 * s2 + b3 * s3, s); // k = 1: sin(2 pi j / 7) = s1, s2, s3
+    const cf n2 = mi_s(b1 * s2 - b2 * s3 - b3 * s1, s); // k = 2: sin(4 pi j / 7) = s2, -s3, -s1
+    const cf n3 = mi_s(b1 * s3 - b2 * s1 + b3 * s2, s); // k = 3: sin(6 pi j / 7) = s3, -s1, s2
+    x[0] = x[0] + a1 + a2 + a3;
+    x[1] = m1 + n1; x[6] = m1 - n1;
+    x[2] = m2 + n2; x[5] = m2 - n2;
+    x[3] = m3 + n3; x[4] = m3 - n3;
+}
 __device__ __forceinline__ void dft8(cf (&x)[10], float s)
 {
     // two radix-4 over the even / odd inputs, then the radix-2 level with W_8^k
@@ -198,6 +217,7 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
         if constexpr (RX == 3) dft3(x, s);
         if constexpr (RX == 4) dft4(x, s);
         if constexpr (RX == 5) dft5(x, s);
+        if constexpr (RX == 7) dft7(x, s);
         if constexpr (RX == 8) dft8(x, s);
         if constexpr (RX == 10) dft10(x, s);
         cf* __restrict__ out = drow + (j - k) * RX + k;
@@ -259,6 +279,7 @@ __device__ __forceinline__ void gen_stage_inplace(cf* __restrict__ img, const cf
             if constexpr (RX == 3) dft3(x[b], s);
             if constexpr (RX == 4) dft4(x[b], s);
             if constexpr (RX == 5) dft5(x[b], s);
+            if constexpr (RX == 7) dft7(x[b], s);
             if constexpr (RX == 8) dft8(x[b], s);
             if constexpr (RX == 10) dft10(x[b], s);
             cf* __restrict__ out = rowp + (j - k) * RX + k;
@@ -300,6 +321,7 @@ __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restri
         case 3: gen_stage<3>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         case 4: gen_stage<4>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         case 5: gen_stage<5>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+        case 7: gen_stage<7>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         case 8: gen_stage<8>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         default: gen_stage<10>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         }

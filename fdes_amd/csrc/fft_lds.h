@@ -108,7 +108,7 @@ bool wave_pass_supported_len(int n);
 bool wave_pass_preferred(int n, int pre, int mid, int post, bool store_transposed);
 hipError_t wave_pass(int n, int pre, int mid, int post, bool store_transposed, const PassArgs& a, hipStream_t st);
 
-// LDS-resident mixed-radix passes for row lengths 2^a 3^b 5^c in [256, 4096] that are not powers of two (fft_gen.hip);
+// LDS-resident mixed-radix passes for row lengths 2^a 3^b 5^c 7^d in [256, 4096] that are not powers of two (fft_gen.hip);
 // their twiddle table is the n roots of unity W_n^k (float2 as 2 floats)
 bool gen_pass_supported_len(int n);
 int gen_pass_rows(int n);

@@ -239,7 +239,7 @@ int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
 
 /* Engine options (before fdes_plan_create).  Unknown keys -> FDES_EINVAL.  (Test / bench-only keys: fdes_abi_test.h.)
  *   "fft"        0 = auto, 1 = rocFFT, 2 = hand-written LDS FFT kernels (grid lengths 256 ... 4096 that are powers of two,
- *                or 2^a 3^b 5^c up to 4096: the 320-, 800- and 1000-point grids of the reference's examples, and the 2560 ... 4000-point
+ *                or 2^a 3^b 5^c 7^d up to 4096: the 320-, 800- and 1000-point grids of the reference's examples, and the 2560 ... 4000-point
  *                grids a .qsc with nx = 1280 ... 2000 gives)
  *   "graph"      1 = replay the slice loop from a hipGraph
  *   "seed"       frozen-phonon seed (reference: 1, src/crystalMaker.cu:292)
