@@ -142,6 +142,7 @@ template <int N, int R, int MODE, int LW, int SW> void run(Bufs& B, int pitch, i
     // correctness
     CK(hipMemcpy(B.g[0], hin.data(), ne * 8, hipMemcpyHostToDevice));
     CK(hipMemset(B.g[1], 0, ne * 8));
+    CK(hipDeviceSynchronize()); // the streams below are non-blocking: they do not wait for the null stream's memset
     hipLaunchKernelGGL(kern, dim3(N / R), dim3(64 * R), ldsb, B.st[0], B.g[0], B.g[1], pitch);
     CK(hipStreamSynchronize(B.st[0]));
     std::vector<float> ho(ne * 2);
