@@ -406,6 +406,33 @@ def run_extras(device):
                                 "frac": round(ENGINE_BYTES_PER_PX_SLICE * px * rate / 8e12, 4)}}
     pl.close()
     eng.close()
+    # A grid length that is not a power of two (round 4): m = 2 nx of a .qsc with nx = 1500 (src/rwQsc.cu:943-948) = 3000, on the
+    # fused mixed-radix passes (until round 3: rocFFT + point-wise kernels); C3 specimen, 32 slices, 2 untimed + 6 timed
+    # configurations, every slice the full sequence
+    hp, at = specimens.case_c3(k=30, n=1500, dn=750, m3=32, frPh=32)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(device, skip_empty=0)
+    pl = eng.plan(hp, at)
+    pl.begin_measurement(0)
+    for j in range(2):
+        pl.run_config(0, 100 + j, 0.0)
+    pl.sync()
+    torch.cuda.synchronize()
+    n = 6
+    t0 = time.perf_counter()
+    for j in range(n):
+        pl.run_config(0, j, 1.0 / 32)
+    pl.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pl.end_measurement(0)
+    img = pl.get_images()
+    out["qsc_sized_grid"] = {"workload": f"C3 specimen ({at.n} atoms) on a 3000x3000 wave (m = 2 nx, nx = 1500), {pl.m3} slices, {n} configurations timed",
+                             "value": round(n * pl.m3 / dt, 1), "unit": "slice-propagations/s", "lanes": pl.lanes(),
+                             "slice_loop": "fused LDS passes" if pl.fft_backend() == 2 else "rocFFT + point-wise kernels",
+                             "finite": bool(np.isfinite(img).all())}
+    pl.close()
+    eng.close()
     # BASELINE config 4 at full size: SrTiO3 beam-tilt series, 64 tilts x 8 frozen-phonon configurations, 1024^2 wave, 40
     # slices, every slice the full sequence; engine defaults (lanes of gangs); one untimed job, one timed job
     hp, at = specimens.case_c4()
