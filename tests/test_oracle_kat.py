@@ -242,3 +242,15 @@ def test_slice_loop_against_an_independent_numpy_multislice(oracle, kw):
     err = np.linalg.norm(psi - ref) / np.linalg.norm(ref)
     assert err < 1e-11, (kw, err)
     assert np.abs(ref - 1).max() > 0.05   # a non-trivial wave
+
+
+def test_single_measurement_entry_equals_the_series(oracle):
+    """oracle.measurement(k) (round 4: the body of buildMeasurements' k loop, src/crystalMaker.cu:324-373, for ONE k) gives the
+    k-th image of the full driver bit for bit: every random stream is keyed on (k, j), nothing is carried from one
+    measurement to the next (pD = 0)."""
+    hp, at = S.case_tiny(m=64, m3=4, nz=2, frPh=2, n3=3, tilt=True, beam_tilt=True)
+    oracle.consistent(hp)
+    for prec in ("f32", "f64"):
+        full = oracle.build_measurements(hp, at, prec=prec)["image"]
+        for k in range(3):
+            assert np.array_equal(oracle.measurement(hp, at, k, prec=prec), full[k]), (prec, k)
