@@ -116,3 +116,39 @@ def test_qsc_sized_grids_beyond_2048_run_the_fused_loop(oracle):
     out = eng.build_measurements(hp, at)["image"]
     eng.close()
     check(out, oracle.build_measurements(hp, at, prec="f32")["image"], None, 2e-5, f"fused loop on a {hp.c.m1} x {hp.c.m2} grid")
+
+
+def test_stage_goldens_and_au309_measurement_12_on_the_gpu():
+    """The committed per-stage goldens (tests/golden/stage_cases.npz: potential of one sub-slice, Fresnel propagator with its
+    band-limit mask) and the exit-wave intensity of measurement k = 12 of the shipped Au-309 example (au309_k12.npz; 320 x 320
+    wave on the mixed-radix passes, 132 sub-slices, specimen tilt 12 of 25) against the engine's taps - fixtures instead of a
+    live oracle run (SURVEY 8c's list)."""
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(G, "stage_cases.npz"))
+    hp, at = S.case_tiny(**S.GOLDEN_CASES["img_2sp"])
+    fdes_amd.consistent(hp)
+    for fft in (1, 0):   # 64 x 64 runs the rocFFT loop either way; the taps are the same code for every path
+        eng = fdes_amd.Engine(0, fft=fft, skip_empty=0)
+        pl = eng.plan(hp, at)
+        check(pl.tap_potential(0, 0, 2), g["potential_s2_f64"], g["potential_s2_f32"], 1e-5, "golden potential of sub-slice 2")
+        check(pl.tap_propagator(), g["propagator_f64"], g["propagator_f32"], 1e-5, "golden Fresnel propagator")
+        assert np.array_equal(np.abs(pl.tap_propagator()) > 0, g["band_mask"].astype(bool))
+        pl.close()
+        eng.close()
+    a = np.load(os.path.join(G, "au309_k12.npz"))
+    hp, at = fdes_amd.read_cnf(os.path.join(G, "dataFDES_Auparticle.cnf"), bug_compatible=False)
+    hp.set(pD=0.0)
+    fdes_amd.consistent(hp)
+    for skip in (0, 1):
+        eng = fdes_amd.Engine(0, skip_empty=skip)
+        pl = eng.plan(hp, at)
+        assert pl.fft_backend() == 2
+        psi = pl.tap_wave(12, 0)
+        check(np.abs(psi) ** 2, a["exit_intensity_f64"], a["exit_intensity_f32"], 1e-4, f"Au-309 k = 12 exit-wave intensity, skip_empty = {skip}")
+        pl.close()
+        eng.close()
+    eng = fdes_amd.Engine(0)
+    img = eng.build_measurements(hp, at)["image"]
+    eng.close()
+    check(img[12], a["image_f64"], None, 1e-4, "Au-309 image of measurement 12 within the whole series")

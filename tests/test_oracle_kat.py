@@ -254,3 +254,39 @@ def test_single_measurement_entry_equals_the_series(oracle):
         full = oracle.build_measurements(hp, at, prec=prec)["image"]
         for k in range(3):
             assert np.array_equal(oracle.measurement(hp, at, k, prec=prec), full[k]), (prec, k)
+
+
+def test_stage_goldens_and_au309_measurement_12(oracle):
+    """SURVEY 8c's remaining fixtures (tools/make_golden.py, our oracle's outputs: the reference holds no such numbers):
+    per-stage goldens at 64 x 64 - potential of one sub-slice, Fresnel propagator + band-limit mask, incoming wave, one full
+    slice step - and the exit-wave intensity / image of measurement k = 12 of the shipped Au-309 example.  The oracle built
+    here reproduces them (float64 to 1e-10; float32 to rounding of the compiler's libm calls)."""
+    import fdes_amd
+    g = np.load(os.path.join(G, "stage_cases.npz"))
+    hp, at = S.case_tiny(**S.GOLDEN_CASES["img_2sp"])
+    oracle.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    xyz = oracle.config_coords(q, at, 0, -1)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    for prec, tol in (("f64", 1e-10), ("f32", 1e-6)):
+        V = oracle.phase_grating(q, at, xyz, 2, prec)
+        P = oracle.fresnel_propagator(q, prec)
+        psi0 = oracle.incoming_wave(q, 0, prec)
+        assert rel(V, g["potential_s2_" + prec]) < tol and rel(P, g["propagator_" + prec]) < tol
+        assert rel(psi0, g["incoming_" + prec]) < tol
+        assert rel(oracle.forward_propagation(q, psi0, V, prec), g["one_step_" + prec]) < tol
+    # the mask is the radial 2/3 limit of zeroHighFreq (src/multisliceSimulation.cu:225-250), in index space
+    m = q.c.m1
+    i = np.fft.fftfreq(m) * m
+    assert np.array_equal(g["band_mask"].astype(bool), (9.0 * (i[None, :] ** 2 + i[:, None] ** 2) / m ** 2) <= 1.0)
+    a = np.load(os.path.join(G, "au309_k12.npz"))
+    hp, at = fdes_amd.read_cnf(os.path.join(G, "dataFDES_Auparticle.cnf"), bug_compatible=False)
+    hp.set(pD=0.0)
+    oracle.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    assert (q.c.m1, q.c.m3, at.n) == (320, 132, 309)
+    psi = oracle.wave(q, at, 12, 0, prec="f64")
+    assert rel(np.abs(psi) ** 2, a["exit_intensity_f64"]) < 1e-10
+    e32 = rel(a["exit_intensity_f32"].astype(np.float64), a["exit_intensity_f64"])
+    print(f"[kat] Au-309 k = 12: float32 oracle vs float64 truth {e32:.2e}")
+    assert e32 < 1e-4
