@@ -10,8 +10,8 @@
 //     association order is fixed by the tree, so the images do not depend on timing;
 //   * FDES_REDUCE=rccl: ONE ncclReduce(sum, float[m1 m2]) to the owner over a communicator created once per
 //     call, for measurements that span ALL GPUs (the frozen-phonon configurations of one image dealt over the node) when
-//     every worker has a device of its own and no exit-wave output is wanted; anything else, and any failure to set the
-//     communicator up, takes the tree.  Not the default: creating a communicator costs more than a whole headline job
+//     every worker has a device of its own (the exit-wave sum of print_level 2 rides along as a second reduce); anything
+//     else, and any failure to set the communicator up, takes the tree.  Not the default: creating a communicator costs more than a whole headline job
 //     (seconds against tens of milliseconds), and RCCL picks the association order.
 // The potential output (print_level > 0) does not depend on (k, j): its slices are dealt over the GPUs.  Random numbers are
 // keyed on (k, j): the images do not depend on the partition beyond the association order of that one sum.
@@ -96,7 +96,7 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
             for (int q = 0; q < r; q++) distinct = distinct && devices[r] != devices[q];
         bool spans_all = false;
         for (int k = 0; k < n3; k++) spans_all = spans_all || (first[(size_t)k] == 0 && last[(size_t)k] == ngpu - 1);
-        want_rccl = mode && !std::strcmp(mode, "rccl") && distinct && spans_all && !exitwave && fdes_comm_unique_id(&comm_id) == FDES_OK;
+        want_rccl = mode && !std::strcmp(mode, "rccl") && distinct && spans_all && fdes_comm_unique_id(&comm_id) == FDES_OK;
     }
     std::vector<fdes_comm*> comms((size_t)ngpu, nullptr);
     std::atomic<int> comm_failures{0}, failed_before_collective{0};

@@ -199,7 +199,8 @@ int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src);
  *                         plans: it allocates device memory, which must not coincide with another thread's graph capture;
  *   fdes_plan_reduce_intensity  EVERY rank of the communicator, for the SAME measurement, in the same order: the ranks'
  *                         running intensity sums (lanes folded, gangs issued) are added onto `root`'s plan, whose sum then
- *                         holds the total; the other ranks' sums are left as they were.  Stream-ordered behind the plan's
+ *                         holds the total; the other ranks' sums are left as they were.  Plans that accumulate the coherent
+ *                         exit-wave sum (fdes_plan_want_exitwave, every rank alike) have it reduced by a second ncclReduce.  Stream-ordered behind the plan's
  *                         work; synchronises.  The order of the additions is RCCL's (fixed for a given node and job shape,
  *                         not the ascending-GPU order of fdes_plan_accumulate_from);
  *   fdes_comm_destroy     after the context's plans are done with it, before fdes_destroy. */

@@ -101,6 +101,7 @@ int fdes_plan_reduce_intensity(fdes_plan* pl, fdes_comm* c, int root)
             if (r == root) continue;
             if (s->cur_k != pl->cur_k) rc = FDES_EINVAL; // every rank must hold the same measurement
             for (size_t i = 0; i < pl->I.size(); i += 2) pl->I[i] += s->I[i]; // the real view only
+            if (pl->want_ew) for (size_t i = 0; i < pl->EW.size(); i++) pl->EW[i] += s->EW[i];
         }
     }
     g_world.wait();
@@ -147,7 +148,7 @@ static int run_case(int ngpu, int n3, int count, bool fail_one, bool rccl = fals
     if (fail_one) dev[(size_t)(ngpu / 2)] = 99;
     const size_t m12 = 64, img = 30;
     std::vector<float> image(img * (size_t)n3, -1.f), pot(2 * m12 * 7, -1.f), ew(2 * m12 * (size_t)n3, -1.f);
-    const int rc = fdes_build_measurements_multi(ngpu, dev.data(), &p, &a, image.data(), pot.data(), rccl ? nullptr : ew.data());
+    const int rc = fdes_build_measurements_multi(ngpu, dev.data(), &p, &a, image.data(), pot.data(), ew.data());
     if (fail_one) return rc == FDES_OK ? 1 : 0; // must report the failure and must not hang
     if (rc != FDES_OK) return 1;
     if (rccl && n3 == 1 && count >= ngpu && g_reduce_calls != reduce_calls_before + 1) return 1; // the collective path was taken
@@ -160,7 +161,7 @@ static int run_case(int ngpu, int n3, int count, bool fail_one, bool rccl = fals
             for (int j = 0; j < cnt; j++) s += (double)w * contrib(k, j, 2 * (i % m12));
             if (std::abs((double)image[(size_t)k * img + i] - s) > 1e-5) bad++;
         }
-    for (int k = 0; k < n3 && !rccl; k++)
+    for (int k = 0; k < n3; k++)
         for (size_t i = 0; i < 2 * m12; i++) {
             double s = 0;
             for (int j = 0; j < cnt; j++) s += (double)w * contrib(k, j, i + 5);

@@ -19,7 +19,8 @@ def test_rccl_reduce_with_one_rank():
     hp, at = S.case_tiny(m=256, m3=4, nz=2, frPh=4, nat=100, tilt=True)
     fdes_amd.consistent(hp)
     eng = fdes_amd.Engine(0)
-    ref = eng.build_measurements(hp, at)["image"]
+    r = eng.build_measurements(hp, at, want_exitwave=True)
+    ref, ref_ew = r["image"], r["exitwave"][0, ..., 0] + 1j * r["exitwave"][0, ..., 1]
     eng.close()
     for opts in (dict(lanes=2, gang=0), dict(lanes=1, gang=2), dict()):
         eng = fdes_amd.Engine(0, **opts)
@@ -27,15 +28,18 @@ def test_rccl_reduce_with_one_rank():
         assert len(uid) == 128
         comm = eng.comm_create(1, 0, uid)
         pl = eng.plan(hp, at)
+        pl.want_exitwave(True)
         pl.begin_measurement(0)
         for j in range(4):
             pl.run_config(0, j, 0.25)
-        pl.reduce_intensity(comm, 0)
+        pl.reduce_intensity(comm, 0)   # (+ the coherent exit-wave sum: a second reduce)
+        ew = pl.get_exitwave()
         pl.end_measurement(0)
         img = pl.get_images()
         e = relerr(img, ref)
-        print(f"[parity] one-rank ncclReduce {opts}: image vs plain run {e:.3e}")
-        assert e < 2e-6   # (the association order of the lane sums only)
+        e2 = relerr(ew, ref_ew)
+        print(f"[parity] one-rank ncclReduce {opts}: image vs plain run {e:.3e}, exit-wave sum {e2:.3e}")
+        assert e < 2e-6 and e2 < 2e-6   # (the association order of the lane sums only)
         pl.close()
         eng.comm_destroy(comm)
         eng.close()
