@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="configurations in flight per GPU (engine option lanes)")
     ap.add_argument("--pass-threads", type=int, default=0)
     ap.add_argument("--split", type=int, default=-1, help="engine option split: potential chain on a stream of its own (-1: engine default)")
+    ap.add_argument("--batch", type=int, default=-1, help="engine option batch: slice pairs per launch of the potential chain (-1: engine default)")
     ap.add_argument("--walk", type=int, default=1, help="engine option walk: row groups per pass workgroup")
     ap.add_argument("--pitch-pad", type=int, default=-1, help="engine option pitch_pad (-1: by grid size)")
     ap.add_argument("--graph", type=int, default=1, help="engine option graph: replay the slice loop as a hipGraph")
@@ -105,6 +106,8 @@ def main():
                               pass_threads=args.pass_threads, skip_empty=skip_empty, pitch_pad=args.pitch_pad, split=args.split)
         eng.set_option("graph", args.graph)
         eng.set_option("walk", args.walk)
+        if args.batch >= 0:
+            eng.set_option("batch", args.batch)
         plan = eng.plan(hp, atoms)
 
         def barrier():
