@@ -140,10 +140,12 @@ hid_t dset(H5& h, hid_t loc, const char* name, hid_t type, int rank, const hsize
     h.Sclose(sp);
     return d;
 }
-void axis(H5& h, hid_t grp, const char* dname, int n, const char* name, const char* units)
+// centred axes: index - (n-1)/2 (x, y everywhere: rwHdf5.cu:108-113, 134-139, 434-437; z of the potential slices: :160-165);
+// frame axes of /data/images and /data/exit_wave are the plain index (float) i (:330-335, 493-498, config writer :1393-1398)
+void axis(H5& h, hid_t grp, const char* dname, int n, const char* name, const char* units, bool centred = true)
 {
     std::vector<float> v((size_t)n);
-    for (int i = 0; i < n; i++) v[i] = (float)(i - (n - 1) / 2.0);
+    for (int i = 0; i < n; i++) v[i] = centred ? (float)(i - (n - 1) / 2.0) : (float)i;
     hsize_t d = (hsize_t)n;
     hid_t ds = dset(h, grp, dname, h.T_FLOAT, 1, &d, v.data());
     if (ds >= 0) { attr_str(h, ds, "name", name); attr_str(h, ds, "units", units); h.Dclose(ds); }
@@ -167,7 +169,7 @@ void vec_dataset(H5& h, hid_t grp, const char* name, hid_t type, size_t n, const
 }
 
 // [slice][y][x][c] -> [x][y][slice][c]   (rwHdf5.cu:80-88, 248-256)
-void complex_stack(H5& h, hid_t grp, const float* src, int m1, int m2, int n)
+void complex_stack(H5& h, hid_t grp, const float* src, int m1, int m2, int n, bool centred_z)
 {
     std::vector<float> t(2 * (size_t)m1 * m2 * n);
     for (int i = 0; i < n; i++)
@@ -182,7 +184,7 @@ void complex_stack(H5& h, hid_t grp, const float* src, int m1, int m2, int n)
     if (ds >= 0) h.Dclose(ds);
     axis(h, grp, "dim1", m1, "x", "[m]");
     axis(h, grp, "dim2", m2, "y", "[m]");
-    axis(h, grp, "dim3", n, "z", "[m]");
+    axis(h, grp, "dim3", n, "z", "[m]", centred_z);
     complex_axis(h, grp);
 }
 
@@ -250,13 +252,13 @@ extern "C" int fdes_write_emd(const char* file, const fdes_params* p, const fdes
     if (print_level > 0 && potential && m123 < 268435456LL) { // rwHdf5.cu:64
         hid_t g = h.Gcreate2(gdata, "potential_slices", 0, 0, 0);
         attr1<unsigned char>(h, g, "emd_group_type", h.T_UCHAR, 1);
-        complex_stack(h, g, potential, p->m1, p->m2, p->m3);
+        complex_stack(h, g, potential, p->m1, p->m2, p->m3, true);
         h.Gclose(g);
     }
     if (print_level > 1 && exitwave) {
         hid_t g = h.Gcreate2(gdata, "exit_wave", 0, 0, 0);
         attr1<unsigned char>(h, g, "emd_group_type", h.T_UCHAR, 1);
-        complex_stack(h, g, exitwave, p->m1, p->m2, p->n3);
+        complex_stack(h, g, exitwave, p->m1, p->m2, p->n3, false);
         h.Gclose(g);
     }
     {
@@ -273,7 +275,7 @@ extern "C" int fdes_write_emd(const char* file, const fdes_params* p, const fdes
         if (ds >= 0) h.Dclose(ds);
         axis(h, g, "dim1", n1, "x", "[m]");
         axis(h, g, "dim2", n2, "y", "[m]");
-        axis(h, g, "dim3", n3, "z", "[m]");
+        axis(h, g, "dim3", n3, "z", "[m]", false);
         h.Gclose(g);
     }
     h.Gclose(gdata);

@@ -35,7 +35,8 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
     if (rc) return rc;
     fdes_atoms atoms = {0, nullptr, nullptr, nullptr, nullptr};
     const bool external = atomsArray != nullptr; // atomsFromExternal, src/FDESExport.cu:73
-    int flags = FDES_CNF_BUG_COMPATIBLE | (external ? FDES_CNF_SKIP_ATOMS : 0);
+    // the file's own atoms are read even when the caller brings a list: the readers echo them (below)
+    int flags = FDES_CNF_BUG_COMPATIBLE;
     if (std::getenv("FDES_STRICT_CNF")) flags &= ~FDES_CNF_BUG_COMPATIBLE;
     rc = is_emd   ? fdes_read_emd(input_name, &p0, &atoms, flags)
          : is_qsc ? fdes_read_qsc(input_name, &p0, &atoms, flags)
@@ -45,17 +46,21 @@ extern "C" int fdes_run_file(int gpu_index, int print_level, const char* input_n
         fdes_params_release(&p0);
         return rc;
     }
-    if (external) {
+    // Parameter echoes happen inside the reference's readers, i.e. with the file's own atoms and after consitentParams:
+    // dataFDES_used.cnf (src/paramStructure.cu:629-631), ParamsUsedQsc.txt (src/rwQsc.cu:1097), ParamsUsedEmd.txt
+    // (src/rwHdf5.cu:2561-2565); a caller-supplied list is echoed as testRead.txt (src/paramStructure.cu:344).
+    rc = fdes_params_consistent(&p0);
+    if (rc == FDES_OK)
+        fdes_write_cnf(is_emd ? "ParamsUsedEmd.txt" : is_qsc ? "ParamsUsedQsc.txt" : "dataFDES_used.cnf", &p0, &atoms);
+    if (rc == FDES_OK && external) {
         rc = fdes_atoms_from_array(&atoms, atomsArray, numAtoms, /*truncate_occ=*/1); // src/paramStructure.cu:323
-        if (rc) { fdes_params_release(&p0); return rc; }
+        if (rc) { fdes_atoms_release(&atoms); fdes_params_release(&p0); return rc; }
         p0.nAt = numAtoms;
+        fdes_write_cnf("testRead.txt", &p0, &atoms);
     }
     std::fprintf(stderr, "  Number of atoms in the specimen: %i\n", atoms.nAt);
-    rc = fdes_params_consistent(&p0);
-    if (rc == FDES_OK && !is_emd) {
-        fdes_write_cnf(is_qsc ? "ParamsUsedQsc.txt" : "dataFDES_used.cnf", &p0, &atoms); // src/paramStructure.cu:629-631, src/rwQsc.cu:1097
-        (void)fdes_write_emd("config.emd", &p0, &atoms, nullptr, nullptr, nullptr, 0); // src/FDES.cu:213, FDESExport.cu:130
-    }
+    if (rc == FDES_OK && !is_emd)
+        (void)fdes_write_emd("config.emd", &p0, &atoms, nullptr, nullptr, nullptr, 0); // confOption != 0: src/FDES.cu:229-232, FDESExport.cu:149-152
     std::vector<float> image, potential, exitwave;
     fdes_ctx* ctx = nullptr;
     // Extension: FDES_DEVICES="0,1,2,3" (or FDES_NUM_GPUS=n: devices gpu_index ... gpu_index + n - 1) spreads the

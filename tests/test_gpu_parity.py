@@ -202,7 +202,10 @@ def test_shipped_style_cnf_through_legacy_symbol(engine, oracle, tmp_path):
         out = np.zeros((hp.c.n3, hp.c.n2, hp.c.n1), np.float32)
         fdes_amd.run_file(str(cnf), "Measurements.bin", "results.emd", atoms=at, out=out)
         disk = np.fromfile("Measurements.bin", np.float32).reshape(out.shape)
-        assert os.path.exists("dataFDES_used.cnf")
+        assert os.path.exists("dataFDES_used.cnf") and os.path.exists("config.emd")
+        # the caller's atom list is echoed as testRead.txt (src/paramStructure.cu:344)
+        _, at_echo = fdes_amd.read_cnf("testRead.txt", bug_compatible=False)
+        assert at_echo.n == at.n and np.array_equal(at_echo.Z, at.Z)
     finally:
         os.chdir(cwd)
     assert np.array_equal(out, disk)
@@ -269,6 +272,10 @@ def test_shipped_au309_example_through_the_cli(oracle, tmp_path):
     if fdes_amd.emd_available():
         hp2, at2 = fdes_amd.read_emd(tmp_path / "results.emd")
         assert hp2.c.n3 == 25 and at2.n == 309
+    # an .emd input echoes its parameters as ParamsUsedEmd.txt (src/rwHdf5.cu:2565) and writes no config.emd (src/FDES.cu:229)
+    used, at_used = fdes_amd.read_cnf(tmp_path / "ParamsUsedEmd.txt", bug_compatible=False)
+    assert at_used.n == 309 and (used.c.n1, used.c.n3, used.c.m3) == (160, 25, 12)
+    assert not os.path.exists(tmp_path / "config.emd")
 
 
 def test_srtio3_qsc_through_the_cli(oracle, tmp_path):

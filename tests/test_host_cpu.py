@@ -356,6 +356,63 @@ def test_write_emd_round_trip_and_layout(tmp_path):
             assert need in names, need
 
 
+@pytest.mark.skipif(not fdes_amd.emd_available(), reason="libhdf5 not loadable")
+def test_config_emd_equals_the_file_the_reference_wrote(tmp_path):
+    """Reference-held golden for the writer schema: ExampleSpecimens/Au_cubeoctahedron_emd/Auparticle.emd was written by the
+    reference's configuration writer (src/rwHdf5.cu:1085-1944, same helpers as the results writer :27-1083) from
+    dataFDES_Auparticle.cnf.  Our writer, fed the same .cnf, must produce the same HDF5 object tree: every group, dataset and
+    attribute name, type (class, size, sign, byte order, string padding), shape and value."""
+    from tests import h5lite
+    hp, at = fdes_amd.read_cnf(os.path.join(ROOT, "tests", "golden", "dataFDES_Auparticle.cnf"), bug_compatible=True)
+    fdes_amd.consistent(hp)
+    out = tmp_path / "config.emd"
+    fdes_amd.write_emd(out, hp, at, None, None, None, print_level=0)
+    ours, ref = h5lite.describe(out), h5lite.describe(EMD_FIXTURE)
+    # 1 ulp on sigma: the file holds the reference binary's value 12279866, consitentParams in float32 gives ...867 (KAT 2)
+    sig = ours["/microscope"]["attrs"]["interaction_constant"]
+    got, want = (np.frombuffer(d["/microscope"]["attrs"]["interaction_constant"]["data"], np.float32)[0] for d in (ours, ref))
+    assert abs(float(got) - float(want)) <= 1.0
+    sig["data"] = ref["/microscope"]["attrs"]["interaction_constant"]["data"]
+    assert h5lite.diff(ours, ref) == []
+    # the frame axis of the images is the plain index (src/rwHdf5.cu:1393-1398), x and y are centred (:1330-1335)
+    assert np.array_equal(np.frombuffer(ours["/data/images/dim3"]["data"], np.float32), np.arange(25, dtype=np.float32))
+    assert np.array_equal(np.frombuffer(ours["/data/images/dim1"]["data"], np.float32), np.arange(160, dtype=np.float32) - 79.5)
+
+
+@pytest.mark.skipif(not fdes_amd.emd_available(), reason="libhdf5 not loadable")
+def test_results_emd_axes(tmp_path):
+    """Results file at print_level 2 (src/rwHdf5.cu:27-1083): images and exit wave carry the frame INDEX as dim3
+    ((float) i, :330-335, 493-498), the potential slices a centred dim3 (i - (m3-1)/2, :160-165); x and y centred everywhere."""
+    from tests import h5lite
+    hp, at = S.case_tiny(m=64, m3=4, nz=2, n3=3, tilt=True)
+    fdes_amd.consistent(hp)
+    c = hp.c
+    rng = np.random.default_rng(1)
+    img = rng.random((c.n3, c.n2, c.n1), np.float32)
+    pot = rng.random((c.m3, c.m2, c.m1, 2), np.float32)
+    ew = rng.random((c.n3, c.m2, c.m1, 2), np.float32)
+    out = tmp_path / "results.emd"
+    fdes_amd.write_emd(out, hp, at, img, pot, ew, print_level=2)
+    d = h5lite.describe(out)
+
+    def ax(name):
+        return np.frombuffer(d[name]["data"], np.float32)
+    assert np.array_equal(ax("/data/images/dim3"), np.arange(c.n3, dtype=np.float32))
+    assert np.array_equal(ax("/data/exit_wave/dim3"), np.arange(c.n3, dtype=np.float32))
+    assert np.array_equal(ax("/data/potential_slices/dim3"), np.arange(c.m3, dtype=np.float32) - np.float32((c.m3 - 1) / 2.0))
+    for g, n in (("images", c.n1), ("exit_wave", c.m1), ("potential_slices", c.m1)):
+        assert np.array_equal(ax(f"/data/{g}/dim1"), (np.arange(n) - (n - 1) / 2.0).astype(np.float32)), g
+        assert np.array_equal(ax(f"/data/{g}/dim2"), (np.arange(n) - (n - 1) / 2.0).astype(np.float32)), g
+    assert d["/data/exit_wave/data"]["shape"] == (c.m1, c.m2, c.n3, 2) and d["/data/potential_slices/data"]["shape"] == (c.m1, c.m2, c.m3, 2)
+    assert d["/data/images/data"]["shape"] == (c.n1, c.n2, c.n3)
+    # data layout without h5dump: /data/images/data is (n1, n2, n3) with x slowest (src/rwHdf5.cu:413-423)
+    got = np.frombuffer(d["/data/images/data"]["data"], np.float32).reshape(c.n1, c.n2, c.n3)
+    assert np.array_equal(got, img.transpose(2, 1, 0))
+    got = np.frombuffer(d["/data/exit_wave/data"]["data"], np.float32).reshape(c.m1, c.m2, c.n3, 2)
+    assert np.array_equal(got, ew.transpose(2, 1, 0, 3))
+    assert d["/data/exit_wave/dim4"]["data"] == b"realimag" and d["/data/exit_wave/dim4"]["type"][:2] == ("string", 4)
+
+
 # ---------------------------------------------------------------------------------------------------
 # .qsc front-end (SURVEY §8 f-3): src/rwQsc.cu + qstem-libs readparam / .cfg reader / replicateUnitCell
 QSC = os.path.join(ROOT, "tests", "golden", "qsc")   # the reference's bin/test.qsc + bin/SrTiO3.cfg (data fixtures)
