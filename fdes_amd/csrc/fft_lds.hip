@@ -828,7 +828,8 @@ hipError_t lds_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
         if (a.band_L != n / 3) a.skip_dead_loads = 0; // the kernel's column classes assume the band of a square grid
     }
     if (gen_pass_supported_len(n)) return gen_pass(n, pre, mid, post, st_t, a, st);
-    if (a.wg != 65 && a.walk <= 1 && wave_pass_preferred(n, pre, mid, post, st_t)) { a.wg = 64; return wave_pass(n, pre, mid, post, st_t, a, st); }
+    // (four rows per workgroup there: a row count the plan's own geometry divides but four does not stays with the kernels below)
+    if (a.wg != 65 && a.walk <= 1 && a.nrows % 4 == 0 && wave_pass_preferred(n, pre, mid, post, st_t)) { a.wg = 64; return wave_pass(n, pre, mid, post, st_t, a, st); }
     if (a.wg == 64 || a.wg == 65 || a.wg == 128) {
         if (wave_pass_supported_len(n) && a.walk <= 1) return wave_pass(n, pre, mid, post, st_t, a, st);
         a.wg = n <= 1024 ? 1 : 256; // rows without such a kernel (or a pass launched in parts, which only the kernels of this file do): one row per thread up to 1024 points, else two rows per thread

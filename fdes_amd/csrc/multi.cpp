@@ -99,7 +99,11 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
         want_rccl = mode && !std::strcmp(mode, "rccl") && distinct && spans_all && fdes_comm_unique_id(&comm_id) == FDES_OK;
     }
     std::vector<fdes_comm*> comms((size_t)ngpu, nullptr);
-    std::atomic<int> comm_failures{0}, failed_before_collective{0};
+    std::atomic<int> comm_failures{0};
+    // per measurement: workers that arrived at k's collective in a failed state (written before k's barrier, read after it: every
+    // rank decides from the same value, and a rank that fails later cannot change the decision a slow peer is still to read)
+    std::vector<std::atomic<int>> failed_before_collective((size_t)n3);
+    for (auto& f : failed_before_collective) f.store(0);
     auto worker = [&](int r) {
         int& rc = status[(size_t)r];
         fdes_ctx* ctx = nullptr;
@@ -137,9 +141,9 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
             }
             if (split && rccl && first[(size_t)k] == 0 && last[(size_t)k] == ngpu - 1) {
                 // one collective; a rank that has failed must not leave the others inside it: all agree first
-                if (rc != FDES_OK) failed_before_collective++;
+                if (rc != FDES_OK) failed_before_collective[(size_t)k]++;
                 bar.wait();
-                if (failed_before_collective.load() == 0) rc = fdes_plan_reduce_intensity(pl, comms[(size_t)r], first[(size_t)k]);
+                if (failed_before_collective[(size_t)k].load() == 0) rc = fdes_plan_reduce_intensity(pl, comms[(size_t)r], first[(size_t)k]);
                 else if (rc == FDES_OK) rc = FDES_EGPU; // a peer failed
             } else if (split) { // every thread passes every barrier, whatever its state, so that nobody waits for ever
                 if (rc != FDES_OK) plans[(size_t)r] = nullptr;

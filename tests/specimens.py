@@ -48,11 +48,11 @@ def make_params(n3=1, **kw):
 
 
 def case_tiny(m=64, m3=4, nz=2, frPh=0, mode=0, n3=1, seed=3, tilt=False, beam_tilt=False, pD=0.0,
-              imPot=0.05, rect=False, nat=40, sub=1, zfrac=0.5):
-    """Small random multi-species specimen on an m x m (rect: m x m/2) grid for fast parity tests."""
+              imPot=0.05, rect=False, nat=40, sub=1, zfrac=0.5, m2=None):
+    """Small random multi-species specimen on an m x m (rect: m x m/2; m2 given: m x m2) grid for fast parity tests."""
     rng = np.random.default_rng(seed)
     m1 = m
-    m2 = m // 2 if rect else m
+    m2 = m2 if m2 else (m // 2 if rect else m)
     dn1, dn2 = m1 // 4, m2 // 4
     d = 0.2e-10
     Zs = np.array([79, 14, 8, 38][:nz], np.int32)

@@ -161,7 +161,8 @@ def test_mixed_radix_fft_against_numpy(engine, shape):
         assert e < 6e-7
 
 
-@pytest.mark.parametrize("m,nz", [(320, 1), (320, 2), (800, 1), (1000, 2), (3000, 1), (2560, 2), (896, 2), (1400, 1)])   # (round 4: two-row tiles beyond 2048 points; 7-smooth lengths)
+@pytest.mark.parametrize("m,nz", [(320, 1), (320, 2), (800, 1), (1000, 2), (3000, 1), (2560, 2), (896, 2), (1400, 1),
+                                  (2880, 1)])   # (round 4: two-row tiles beyond 2048 points; 7-smooth lengths; round 5: 2880 = a length without compile-time specialisation beyond 2048)
 def test_mixed_radix_slice_loop(oracle, m, nz):
     """The fused slice loop on 320 / 800 / 1000-point grids (before round 3: rocFFT + point-wise kernels, 24 launches per
     slice): exit wave after an odd number of slices and the potential of both members of a pair against the float64
