@@ -63,6 +63,7 @@ struct fdes_ctx {
     int deterministic = 1; // the deposit of the generic (rocFFT) path and of the potential output adds the atoms in sorted order through LDS (bit-reproducible); 0: global float atomics as the reference
     int peer_copy = 1;    // 0: fdes_plan_accumulate_from stages partial sums through host memory instead of a peer copy (the fallback path, forced)
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
+    int probe_pass = 5;   // fused loop: the pass class that is bracketed (1 = P1' ... 6 = P6; bench.py's per-pass table)
     // plans are expensive to create: one per grid size AND requested back-end (option "fft" may change between plans)
     std::map<std::tuple<int, int, int>, Fft2D*> fft_cache;
     // plans created on this context and not yet destroyed: fdes_destroy takes them down first, so a host that forgets
@@ -477,6 +478,26 @@ void gang_strides(const fdes_plan* pl, PassArgs& a, size_t in0, size_t out, size
     a.bstride_in0 = in0; a.bstride_out = out; a.bstride_out2 = out2; a.bstride_in1 = in1;
 }
 
+// roofline probe (bench.py): every probe_stride-th launch of the pass class the context's probe_pass names (1 = P1', 2 = P2,
+// 3 = P3, 4 = P4, 5 = P5, 6 = P6) is bracketed by the start / stop events of the dispatch itself (hipExtLaunchKernelGGL)
+int probe_bracket(fdes_plan* pl, PassArgs& a, int cls)
+{
+    fdes_ctx* c = pl->ctx;
+    const fdes_ctx* oc = owner_ctx(pl);
+    if (pl->capturing || oc->probe_stride <= 0 || oc->probe_pass != cls) return FDES_OK;
+    if ((pl->fft_calls++ % (uint64_t)oc->probe_stride) != 0) return FDES_OK;
+    if (pl->probe_used == pl->probe.size()) {
+        EvPair e{};
+        HIPCHK(c, hipEventCreate(&e.a));
+        HIPCHK(c, hipEventCreate(&e.b));
+        pl->probe.push_back(e);
+    }
+    EvPair* ev = &pl->probe[pl->probe_used++];
+    a.ev_start = ev->a;
+    a.ev_stop = ev->b;
+    return FDES_OK;
+}
+
 // Potential of the slice PAIR (s0, s0 + 1), s0 even: W = V_s0 + i V_(s0+1) (the deposits are real and the filter
 // G is real and even, so one complex transform carries two slices).  P1' builds the x-spectra of the deposit rows
 // straight from the sorted atom records (no deposit grid), P2 applies the filter in (kx, ky) and sums the species.
@@ -496,11 +517,13 @@ int fused_potential_pair(fdes_plan* pl, int s0)
             a.bstride_recs = pl->recs_stride; a.bstride_rowstart = pl->rowstart_stride;
             for (int g = 0; g < pl->gn; g++) { a.zq0[g] = a.q0; a.zq1[g] = a.q1; }
         }
+        RC(probe_bracket(pl, a, 1));
         HIPCHK(c, lds_pass(m1, XF_FWD, MID_ATOMS, XF_NONE, true, a, vstream(pl)));
     }
     PassArgs b = pass_y(pl);
     b.in0 = pl->A; b.gtab = pl->GT; b.out = pl->B; b.nspecies = pl->nZ; b.species_stride = pl->gsz;
     gang_strides(pl, b, pl->gsz * (size_t)pl->nZ, pl->gsz);
+    RC(probe_bracket(pl, b, 2));
     HIPCHK(c, lds_pass(m2, XF_FWD, pl->nZ == 1 ? MID_GTAB : MID_GTABN, XF_INV, true, b, vstream(pl)));
     return FDES_OK;
 }
@@ -587,21 +610,7 @@ int fused_wave_step(fdes_plan* pl, int s, const float2* E, int ei)
     // and which is not band-limited in kx when a tilted CBED probe leaves the band (:583-590) - then all of it is read.
     a5.band = band; a5.skip_dead_loads = bs ? ((s == 0 && !pl->wave_bl) ? 1 : 3) : 0; a5.skip_dead_stores = bs;
     gang_strides(pl, a5, pl->gsz, pl->gsz, 0, pl->gsz);
-    // roofline probe: P5 is the longest kernel of the loop; every probe_stride-th launch is bracketed by events
-    const int pstride = owner_ctx(pl)->probe_stride;
-    const bool probe = !pl->capturing && pstride > 0 && (pl->fft_calls++ % (uint64_t)pstride) == 0;
-    EvPair* ev = nullptr;
-    if (probe) {
-        if (pl->probe_used == pl->probe.size()) {
-            EvPair e{};
-            HIPCHK(c, hipEventCreate(&e.a));
-            HIPCHK(c, hipEventCreate(&e.b));
-            pl->probe.push_back(e);
-        }
-        ev = &pl->probe[pl->probe_used++];
-        a5.ev_start = ev->a; // timestamps of the dispatch itself (hipExtLaunchKernelGGL)
-        a5.ev_stop = ev->b;
-    }
+    RC(probe_bracket(pl, a5, 5));
     HIPCHK(c, lds_pass(m1, XF_INV, MID_MULPSI, XF_FWD, true, a5, c->stream));
     if (ei >= 0) {
         HIPCHK(c, hipEventRecord(pl->evP5[ei], c->stream));
@@ -611,6 +620,7 @@ int fused_wave_step(fdes_plan* pl, int s, const float2* E, int ei)
     a6.in0 = pl->F; a6.prow = pl->PT; a6.pcol = pl->PT + m1; a6.mindim = md; a6.out = pl->PSIH;
     a6.band = band; a6.live_rows_only = bs;
     gang_strides(pl, a6, pl->gsz, pl->gsz);
+    RC(probe_bracket(pl, a6, 6));
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_PTAB, XF_INV, true, a6, c->stream));
     return FDES_OK;
 }
@@ -637,6 +647,7 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
         a3.in0 = pl->B; a3.out = pl->C; a3.out2 = pl->C2; a3.scale = pl->p.imPot;
         a3.band = band; a3.skip_dead_stores = bs;
         gang_strides(pl, a3, pl->gsz, pl->gsz, pl->gsz);
+        RC(probe_bracket(pl, a3, 3));
         HIPCHK(c, lds_pass(m1, XF_INV, MID_EXPIV_PAIR, XF_FWD, true, a3, vstream(pl)));
     }
     const bool split = pl->split && !pl->tap_mode;
@@ -646,6 +657,7 @@ int fused_slice(fdes_plan* pl, int s, int nslices, int* consumed)
     a4.band = band; a4.live_rows_only = bs;
     gang_strides(pl, a4, pl->gsz, pl->gsz);
     if (split && pl->p5_seen[ei]) HIPCHK(c, hipStreamWaitEvent(pl->vs, pl->evP5[ei], 0)); // the wave chain has consumed this buffer
+    RC(probe_bracket(pl, a4, 4));
     HIPCHK(c, lds_pass(m2, XF_FWD, MID_MASK, XF_INV, true, a4, vstream(pl)));
     if (split) {
         HIPCHK(c, hipEventRecord(pl->evE[ei], pl->vs));
@@ -1418,7 +1430,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "split")) { if (value < -1 || value > 1) return FDES_EINVAL; c->split = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "gang")) { if (value < -1 || value > 16) return FDES_EINVAL; c->gang = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "batch")) { if (value < -1 || value > 8) return FDES_EINVAL; c->batch = (int)value; return FDES_OK; }
-    if (!std::strcmp(key, "stagger")) { if (value < 0 || value > 1024) return FDES_EINVAL; c->stagger = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "stagger")) { if (value < -2048 || value > 1024) return FDES_EINVAL; c->stagger = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "walk")) { if (value < 1 || value > 8) return FDES_EINVAL; c->walk = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "pitch_pad")) { if (value < -1 || value > 1024 || (value > 0 && value % 2)) return FDES_EINVAL; c->pitch_pad = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "band_skip")) { c->band_skip = value != 0; return FDES_OK; }
@@ -1435,6 +1447,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "bench_serial")) { c->bench_serial = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "bench_pitch")) { if (value < 0 || value > 4096) return FDES_EINVAL; c->bench_pitch = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "probe_stride")) { c->probe_stride = (int)value; return FDES_OK; }
+    if (!std::strcmp(key, "probe_pass")) { if (value < 1 || value > 6) return FDES_EINVAL; c->probe_pass = (int)value; return FDES_OK; }
 #endif
     return FDES_EINVAL;
 }
@@ -1724,7 +1737,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
             PLCHK(create_ctx(&lc, c->device, nlanes >= 3 ? l % 3 : 0)); // (every assignment of the three classes to a fourth lane measured the same)
             lc->is_lane_ctx = true;
             // frozen here: fft, lanes, pass_threads (they shape the lane plan); the others are read through owner_ctx()
-            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad; lc->split = pl->split ? 1 : 0; lc->batch = c->batch > 1 ? c->batch : 0; lc->gang = pl->gang; lc->walk = c->walk;
+            lc->opt_fft = c->opt_fft; lc->opt_graph = c->opt_graph; lc->seed = c->seed; lc->probe_stride = c->probe_stride; lc->probe_pass = c->probe_pass; lc->pass_threads = c->pass_threads; lc->lanes = c->lanes; lc->skip_empty = c->skip_empty; lc->band_skip = c->band_skip; lc->pitch_pad = c->pitch_pad; lc->split = pl->split ? 1 : 0; lc->batch = c->batch > 1 ? c->batch : 0; lc->gang = pl->gang; lc->walk = c->walk;
             lc->share_PT = pl->PT; lc->share_GT = pl->GT; // read-only tables of the parent plan (built and synchronised above)
             pl->lane_ctx.push_back(lc);
             fdes_plan* lp = nullptr;

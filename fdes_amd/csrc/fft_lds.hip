@@ -351,6 +351,10 @@ __device__ __forceinline__ void pass_body(const PassArgs& A, float2* __restrict_
     if (A.stagger > 0 && A.ncu > 0 && ((vb / A.ncu) & 1) && vb < 2 * A.ncu) {
         for (int i = 0; i < A.stagger; i++) __builtin_amdgcn_s_sleep(1);
     }
+    // stagger < 0 (round 5): the CUs of the CHIP in different phases.  All workgroups of a pass start together, so all CUs
+    // request their rows together (the memory system at its limit), then all transform (memory idle), then all store: the
+    // first generation on the odd CUs starts -stagger x 64 cycles late, later generations inherit the offset.
+    if (A.stagger < 0 && A.ncu > 0 && vb < A.ncu * (WGeo<WG>::THR == 512 ? 1 : 2)) cu_class_delay(-A.stagger);
     // this thread's stage twiddles (they serve every transform of the pass and both rows); issued first so that their
     // latency hides behind the row loads.  Per row group: hoisted out of the walk loop they would stay live across the
     // whole body and cost more registers than the reload does time.

@@ -510,7 +510,8 @@ __device__ __forceinline__ int live_cols(int i2, int md2)
 template <int N, int MID, bool PIPE> constexpr bool whalfx()
 {
     return ((N == 2048 && !PIPE && (((FDES_W_HALFX & 1) && MID == MID_MASK) || ((FDES_W_HALFX & 2) && MID == MID_PTAB))) ||
-            (N == 4096 && !PIPE && (((FDES_W_HALFX & 4) && MID == MID_MASK) || ((FDES_W_HALFX & 8) && MID == MID_PTAB) || ((FDES_W_HALFX & 16) && MID == MID_GTAB))));
+            (N == 4096 && !PIPE && (((FDES_W_HALFX & 4) && MID == MID_MASK) || ((FDES_W_HALFX & 8) && MID == MID_PTAB) || ((FDES_W_HALFX & 16) && MID == MID_GTAB) ||
+                                     ((FDES_W_HALFX & 32) && MID == MID_EXPIV_PAIR) || ((FDES_W_HALFX & 64) && MID == MID_ATOMS))));
 }
 template <int N, int MID, bool PIPE> constexpr size_t wlds_bytes()
 {
@@ -532,6 +533,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
     const int vstride = PIPE ? (int)gridDim.x : nvirt; // gridDim.x is a multiple of 8 when a workgroup walks (vb % 8 = blockIdx.x % 8)
     // staggered start: wave w of the s-th workgroup of a CU (taken as vb / ncu: workgroups are dealt breadth first; for
     // speed only) starts (w + R s) * stagger * 64 cycles late, so that the rows of a CU are in different phases
+    if (A.stagger < 0 && A.ncu > 0 && vb < A.ncu * (int)(N <= 1024 ? 4 : (whalfx<N, MID, PIPE>() ? (N <= 2048 ? 4 : 2) : ((N <= 2048 && !PIPE) ? 2 : 1)))) cu_class_delay(-A.stagger); // fft_dev.inc: the CUs of the chip in different phases
     if (A.stagger > 0) {
         const int slot = A.ncu > 0 ? vb / A.ncu : 0;
         const int n = (w + R * (slot & 1)) * A.stagger;
@@ -973,7 +975,10 @@ bool wave_pass_supported_len(int n) { return n == 1024 || n == 2048 || n == 4096
 // 4096 points (half-size LDS regions, above)
 bool wave_pass_preferred(int n, int pre, int mid, int post, bool st_t)
 {
-    if (!(n == 4096 && st_t && pre == XF_FWD && post == XF_INV)) return false;
+    if (!(n == 4096 && st_t)) return false;
+    if (pre == XF_INV && post == XF_FWD) return mid == MID_EXPIV_PAIR && whalfx<4096, MID_EXPIV_PAIR, false>();
+    if (pre == XF_FWD && post == XF_NONE) return mid == MID_ATOMS && whalfx<4096, MID_ATOMS, false>();
+    if (!(pre == XF_FWD && post == XF_INV)) return false;
     return (mid == MID_MASK && whalfx<4096, MID_MASK, false>()) || (mid == MID_PTAB && whalfx<4096, MID_PTAB, false>()) ||
            (mid == MID_GTAB && whalfx<4096, MID_GTAB, false>());
 }
