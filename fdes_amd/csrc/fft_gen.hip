@@ -37,12 +37,60 @@ struct GenFac {
     unsigned magic[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// Round 5: the compile-time lengths beyond 1024 points run THREE stages with composite radices (12 = 3 x 4, 15 = 3 x 5,
+// 16 = 4 x 4, 20 = 4 x 5, 25 = 5 x 5 as two levels of small butterflies inside a thread) instead of four or five of radix
+// <= 10: a stage is one trip of the whole tile through LDS (the VGPR -> LDS path, about 85 B/clk/CU, is what these kernels
+// are bound by), so a third fewer stages is a third less of that traffic.  First radix odd where the length allows it: the
+// first stage writes element i of butterfly j to j RX + i, a stride of 2 RX dwords between lanes, conflict-free for odd RX.
+#ifndef FDES_GEN_SPECIALISED
+#define FDES_GEN_SPECIALISED 1 // compile-time kernels for the grids the reference ships and a few round ones (gen_pass below)
+#endif
+#ifndef FDES_GEN_CHAIN
+#define FDES_GEN_CHAIN 1
+#endif
+#ifndef FDES_GEN_PREFETCH_B
+#define FDES_GEN_PREFETCH_B 1 // product pass of the chained kernels: both operands requested before the first transform
+#endif
+__host__ __device__ constexpr bool gen_three_stages(int n, int (&r)[3])
+{
+    switch (n) {
+    case 1280: r[0] = 5; r[1] = 16; r[2] = 16; return true;
+    case 1600: r[0] = 5; r[1] = 16; r[2] = 20; return true;
+    case 2000: r[0] = 5; r[1] = 20; r[2] = 20; return true;
+    case 2560: r[0] = 10; r[1] = 16; r[2] = 16; return true;
+    case 3000: r[0] = 15; r[1] = 10; r[2] = 20; return true;
+    case 3072: r[0] = 12; r[1] = 16; r[2] = 16; return true;
+    case 3200: r[0] = 10; r[1] = 16; r[2] = 20; return true;
+    case 3600: r[0] = 15; r[1] = 16; r[2] = 15; return true;
+    case 4000: r[0] = 10; r[1] = 20; r[2] = 20; return true;
+    default: return false;
+    }
+}
+
 // factors and stage tables of an n-point row; false if n has a prime factor above 7 or more than 8 stages
 __host__ __device__ constexpr bool factorize(int n, GenFac& f)
 {
     f.n = n;
     f.nf = 0;
     int m = n;
+#if FDES_GEN_CHAIN && FDES_GEN_SPECIALISED
+    {   // three stages for the compile-time lengths beyond 1024 points (composite radices 12, 15, 16, 20, 25: round 5)
+        int cr[3] = {0, 0, 0};
+        if (gen_three_stages(n, cr)) {
+            int Ns = 1;
+            for (int q = 0; q < 3; q++) {
+                f.radix[q] = cr[q];
+                f.nbf[q] = n / cr[q];
+                f.ns[q] = Ns;
+                f.tws[q] = n / (Ns * cr[q]);
+                f.magic[q] = (unsigned)(((1ull << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
+                Ns *= cr[q];
+            }
+            f.nf = 3;
+            return Ns == n;
+        }
+    }
+#endif
     // large radices first: fewer stages (each stage is one trip of the tile through LDS)
     const int cand[7] = {10, 8, 7, 5, 4, 3, 2};
     for (int ci = 0; ci < 7; ci++)
@@ -237,37 +285,185 @@ __host__ __device__ constexpr int gen_tw_mode(int n, int rows, bool one_image)
     return 0;
 }
 
-// The same stage IN PLACE (compile-time lengths beyond 1024 points, round 4): a thread first takes the inputs of ALL its
-// butterflies into registers (at most NBT = ceil(n / 2 / tpr) butterflies of radix >= 2: a few dozen registers), the row's
-// threads meet, then it transforms and writes them back to the SAME image.  One image instead of two halves the LDS of a
-// workgroup: two workgroups per CU where the two-image form admits one (1280 ... 4000-point rows), at the price of a second
-// barrier per stage.
-template <int RX, int NBT, bool HALF_TW>
-__device__ __forceinline__ void gen_stage_inplace(cf* __restrict__ img, const cf* __restrict__ twl, const int N, const int nb, const int Ns,
-                                                  const int tws, const unsigned magic, const float s, const int row, const int jt, const int tpr)
+// ---- butterflies of any supported radix on RX registers of a thread (round 5) ------------------------------------------
+// Compile-time roots of unity for the composite radices: cos / sin (2 pi m / M) from a Taylor series in double precision
+// (|angle| <= pi: 1e-15 absolute), multiples of a quarter turn exact.
+constexpr double ct_pi = 3.14159265358979323846264338327950288;
+constexpr double ct_angle(int m, int M) { m %= M; if (2 * m > M) m -= M; return 2.0 * ct_pi * (double)m / (double)M; }
+constexpr double ct_cos(int m, int M)
 {
-    cf* __restrict__ rowp = img + row * N;
-    cf x[NBT][10];
+    m = ((m % M) + M) % M;
+    if ((4 * m) % M == 0) { const int q = 4 * m / M; return q == 0 ? 1.0 : (q == 2 ? -1.0 : 0.0); }
+    const double x = ct_angle(m, M), x2 = x * x;
+    double t = 1.0, r = 1.0;
+    for (int n = 1; n <= 16; n++) { t *= -x2 / (double)((2 * n - 1) * (2 * n)); r += t; }
+    return r;
+}
+constexpr double ct_sin(int m, int M)
+{
+    m = ((m % M) + M) % M;
+    if ((4 * m) % M == 0) { const int q = 4 * m / M; return q == 1 ? 1.0 : (q == 3 ? -1.0 : 0.0); }
+    const double x = ct_angle(m, M), x2 = x * x;
+    double t = x, r = x;
+    for (int n = 1; n <= 16; n++) { t *= -x2 / (double)((2 * n) * (2 * n + 1)); r += t; }
+    return r;
+}
+template <int M> struct CtRoots {
+    float c[M], s[M];
+    constexpr CtRoots() : c(), s()
+    {
+        for (int m = 0; m < M; m++) { c[m] = (float)ct_cos(m, M); s[m] = (float)ct_sin(m, M); }
+    }
+};
+// small butterflies on named registers
+__device__ __forceinline__ void pdft3(cf& x0, cf& x1, cf& x2, float s)
+{
+    const cf t1 = x1 + x2;
+    const cf t2 = x0 - t1 * 0.5f;
+    const cf t3 = mi_s((x1 - x2) * 0.866025403784438647f, s);
+    x0 = x0 + t1;
+    x1 = t2 + t3;
+    x2 = t2 - t3;
+}
+__device__ __forceinline__ void pdft4(cf& x0, cf& x1, cf& x2, cf& x3, float s)
+{
+    const cf a = x0 + x2, b = x0 - x2, c = x1 + x3, d = mi_s(x1 - x3, s);
+    x0 = a + c;
+    x1 = b + d;
+    x2 = a - c;
+    x3 = b - d;
+}
+// R-point DFT in place on x[0], x[ST], x[2 ST], ... (R = 2 ... 5)
+template <int R, int ST> __device__ __forceinline__ void pdft(cf* x, float s)
+{
+    if constexpr (R == 2) { const cf t = x[0] - x[ST]; x[0] = x[0] + x[ST]; x[ST] = t; }
+    if constexpr (R == 3) pdft3(x[0], x[ST], x[2 * ST], s);
+    if constexpr (R == 4) pdft4(x[0], x[ST], x[2 * ST], x[3 * ST], s);
+    if constexpr (R == 5) dft5_(x[0], x[ST], x[2 * ST], x[3 * ST], x[4 * ST], s);
+}
+// M = A B points in place: input n = B n1 + n2 in x[n]; A-point butterflies over n1, twiddle W_M^(n2 k1), B-point butterflies
+// over n2; output X[k1 + A k2] is left in x[B k1 + k2] (rdx_slot below: no register is moved)
+template <int A, int B> __device__ __forceinline__ void cdft(cf* x, float s)
+{
+    constexpr int M = A * B;
+    constexpr CtRoots<M> W{};
 #pragma unroll
-    for (int b = 0; b < NBT; b++) {
-        const int j = jt + b * tpr;
-        if (j < nb) {
+    for (int n2 = 0; n2 < B; n2++) {
+        pdft<A, B>(x + n2, s);
 #pragma unroll
-            for (int i = 0; i < RX; i++) x[b][i] = rowp[j + i * nb];
+        for (int k1 = 1; k1 < A; k1++) {
+            const int m = (n2 * k1) % M;
+            if (m == 0) continue;
+            cf& v = x[n2 + B * k1];
+            if ((4 * m) % M == 0) {
+                const int q = 4 * m / M; // W^m = (-i)^q forward
+                v = q == 1 ? mi_s(v, s) : (q == 2 ? -v : -mi_s(v, s));
+            } else {
+                v = rot_s(v, W.c[m], W.s[m], s);
+            }
         }
     }
-    __syncthreads(); // every input of the stage has been read
 #pragma unroll
-    for (int b = 0; b < NBT; b++) {
-        const int j = jt + b * tpr;
-        if (j < nb) {
-            const int k = (Ns > 1) ? j - (int)__umulhi((unsigned)j, magic) * Ns : 0;
-            if (Ns > 1) {
-                const int dk = k * tws;
+    for (int k1 = 0; k1 < A; k1++) pdft<B, 1>(x + B * k1, s);
+}
+constexpr bool rdx_composite(int rx) { return rx == 12 || rx == 15 || rx == 16 || rx == 20 || rx == 25; }
+constexpr int rdx_a(int rx) { return rx == 12 ? 3 : (rx == 15 ? 3 : (rx == 16 ? 4 : (rx == 20 ? 4 : 5))); }
+// register of a thread's butterfly that holds output i of an RX-point butterfly (rdx_dft)
+template <int RX> __host__ __device__ constexpr int rdx_slot(int i)
+{
+    if constexpr (rdx_composite(RX)) return (RX / rdx_a(RX)) * (i % rdx_a(RX)) + i / rdx_a(RX);
+    else return i;
+}
+template <int RX> __device__ __forceinline__ void rdx_dft(cf (&x)[RX], float s)
+{
+    if constexpr (RX == 2 || RX == 3 || RX == 4 || RX == 5) pdft<RX, 1>(x, s);
+    else if constexpr (RX == 7 || RX == 8 || RX == 10) {
+        cf t[10];
 #pragma unroll
-                for (int i = 1; i < RX; i++) {
-                    if constexpr (HALF_TW) { // the table holds W_N^m for m < N / 2 only: W_N^(m + N/2) = -W_N^m
-                        const int m = i * dk, h = N >> 1;
+        for (int i = 0; i < RX; i++) t[i] = x[i];
+        if constexpr (RX == 7) dft7(t, s);
+        if constexpr (RX == 8) dft8(t, s);
+        if constexpr (RX == 10) dft10(t, s);
+#pragma unroll
+        for (int i = 0; i < RX; i++) x[i] = t[i];
+    } else {
+        static_assert(rdx_composite(RX), "radix");
+        cdft<rdx_a(RX), RX / rdx_a(RX)>(x, s);
+    }
+}
+
+// One stage of the compile-time kernels, IN PLACE (round 4) and in three pieces (round 5): a thread takes the inputs of ALL
+// its butterflies into registers (NBT = ceil(nb / tpr) butterflies of RX elements: the thread's share of the row), transforms
+// them, and writes them back to the SAME image at the Stockham positions; the row's threads meet between the reads and the
+// writes.  One image instead of two halves the LDS of a workgroup: two workgroups per CU where the two-image form admits one.
+// The pieces let a transform take its first stage's inputs straight from global memory (element j + i nb of a row: consecutive
+// threads read consecutive elements) and leave its last stage's outputs in registers, where the point-wise operation of the
+// pass finds them: two trips of the tile through LDS fewer per transform pair.
+template <int NC, int Q> struct GStage {
+    static constexpr GenFac F = make_fac(NC);
+    static constexpr int RX = F.radix[Q], nb = F.nbf[Q], Ns = F.ns[Q], tws = F.tws[Q];
+    static constexpr unsigned magic = F.magic[Q];
+    static constexpr int tpr = kGenThreads >> F.lrows;
+    static constexpr int NBT = (nb + tpr - 1) / tpr;
+    static constexpr bool half_tw = gen_tw_mode(NC, F.rows, true) == 2;
+    static constexpr bool last = Q + 1 == F.nf;
+};
+template <int NC, int Q> using XArr = cf[GStage<NC, Q>::NBT][GStage<NC, Q>::RX]; // a thread's registers of stage Q
+template <int NC, int Q> __device__ __forceinline__ int gs_k(int j)
+{
+    using S = GStage<NC, Q>;
+    return (S::Ns > 1) ? j - (int)__umulhi((unsigned)j, S::magic) * S::Ns : 0;
+}
+// column of output i of butterfly j after stage Q
+template <int NC, int Q> __device__ __forceinline__ int gs_out_col(int j, int i)
+{
+    using S = GStage<NC, Q>;
+    const int k = gs_k<NC, Q>(j);
+    return (j - k) * S::RX + k + i * S::Ns;
+}
+template <int NC, int Q> __device__ __forceinline__ void gs_load_lds(XArr<NC, Q>& x, const cf* __restrict__ rowp, const int jt)
+{
+    using S = GStage<NC, Q>;
+#pragma unroll
+    for (int b = 0; b < S::NBT; b++) {
+        const int j = jt + b * S::tpr;
+        if (j < S::nb) {
+#pragma unroll
+            for (int i = 0; i < S::RX; i++) x[b][i] = rowp[j + i * S::nb];
+        }
+    }
+}
+// from a row in global memory; `band`: columns beyond the band limit count as zero and are not fetched
+template <int NC, int Q> __device__ __forceinline__ void gs_load_global(XArr<NC, Q>& x, const cf* __restrict__ grow, const int jt,
+                                                                         const bool band, const int bandv)
+{
+    using S = GStage<NC, Q>;
+#pragma unroll
+    for (int b = 0; b < S::NBT; b++) {
+        const int j = jt + b * S::tpr;
+        if (j < S::nb) {
+#pragma unroll
+            for (int i = 0; i < S::RX; i++) {
+                const int c = j + i * S::nb;
+                const bool dead = band && dead_index(iwc(c, NC), bandv);
+                x[b][i] = dead ? cf{0.f, 0.f} : grow[c];
+            }
+        }
+    }
+}
+template <int NC, int Q> __device__ __forceinline__ void gs_compute(XArr<NC, Q>& x, const cf* __restrict__ twl, const float s, const int jt)
+{
+    using S = GStage<NC, Q>;
+#pragma unroll
+    for (int b = 0; b < S::NBT; b++) {
+        const int j = jt + b * S::tpr;
+        if (j < S::nb) {
+            if constexpr (S::Ns > 1) {
+                const int dk = gs_k<NC, Q>(j) * S::tws; // i k tws < N: the table index needs no reduction
+#pragma unroll
+                for (int i = 1; i < S::RX; i++) {
+                    if constexpr (S::half_tw) { // the table holds W_N^m for m < N / 2 only: W_N^(m + N/2) = -W_N^m
+                        const int m = i * dk, h = NC >> 1;
                         const cf w = twl[m >= h ? m - h : m];
                         x[b][i] = wmul_s(x[b][i], m >= h ? -w : w, s);
                     } else {
@@ -275,28 +471,66 @@ __device__ __forceinline__ void gen_stage_inplace(cf* __restrict__ img, const cf
                     }
                 }
             }
-            if constexpr (RX == 2) dft2(x[b]);
-            if constexpr (RX == 3) dft3(x[b], s);
-            if constexpr (RX == 4) dft4(x[b], s);
-            if constexpr (RX == 5) dft5(x[b], s);
-            if constexpr (RX == 7) dft7(x[b], s);
-            if constexpr (RX == 8) dft8(x[b], s);
-            if constexpr (RX == 10) dft10(x[b], s);
-            cf* __restrict__ out = rowp + (j - k) * RX + k;
-#pragma unroll
-            for (int i = 0; i < RX; i++) out[i * Ns] = x[b][i];
+            rdx_dft<S::RX>(x[b], s);
         }
     }
 }
-// all stages of an NC-point row in place; the recursion makes every stage's radix and butterfly count per thread constants
+template <int NC, int Q> __device__ __forceinline__ void gs_store_lds(const XArr<NC, Q>& x, cf* __restrict__ rowp, const int jt)
+{
+    using S = GStage<NC, Q>;
+#pragma unroll
+    for (int b = 0; b < S::NBT; b++) {
+        const int j = jt + b * S::tpr;
+        if (j < S::nb) {
+            cf* __restrict__ out = rowp + gs_out_col<NC, Q>(j, 0);
+#pragma unroll
+            for (int i = 0; i < S::RX; i++) out[i * S::Ns] = x[b][rdx_slot<S::RX>(i)];
+        }
+    }
+}
+// all stages of an NC-point row in place, image to image
 template <int NC, int Q> __device__ __forceinline__ void gen_inplace_stages(cf* __restrict__ img, const cf* __restrict__ twl, const float s, const int row, const int jt)
 {
     constexpr GenFac F = make_fac(NC);
     if constexpr (Q < F.nf) {
-        constexpr int RX = F.radix[Q], nb = F.nbf[Q], tpr = kGenThreads >> F.lrows, NBT = (nb + tpr - 1) / tpr;
-        gen_stage_inplace<RX, NBT, gen_tw_mode(NC, F.rows, true) == 2>(img, twl, F.n, nb, F.ns[Q], F.tws[Q], F.magic[Q], s, row, jt, tpr);
+        cf x[GStage<NC, Q>::NBT][GStage<NC, Q>::RX];
+        gs_load_lds<NC, Q>(x, img + row * NC, jt);
+        __syncthreads(); // every input of the stage has been read
+        gs_compute<NC, Q>(x, twl, s, jt);
+        gs_store_lds<NC, Q>(x, img + row * NC, jt);
         __syncthreads();
         gen_inplace_stages<NC, Q + 1>(img, twl, s, row, jt);
+    }
+}
+// The stages Q ... nf - 2 image to image, then the last stage from the image into the caller's registers `xl` (round 5).
+// FROM_GLOBAL (Q = 0 only): the first stage reads its inputs from `grow` instead of the image (nothing of the image is read
+// before the first barrier, but other threads may still be reading what the PREVIOUS phase left there: the caller has passed a
+// barrier since).
+template <int NC, int Q, bool FROM_GLOBAL, bool PRELOADED = false>
+__device__ __forceinline__ void gen_chain_to_regs(cf* __restrict__ img, const cf* __restrict__ grow, const bool band, const int bandv, const cf* __restrict__ twl,
+                                                  const float s, const int row, const int jt, XArr<NC, make_fac(NC).nf - 1>& xl, XArr<NC, 0>& x0)
+{
+    constexpr GenFac F = make_fac(NC);
+    if constexpr (Q + 1 < F.nf) {
+        if constexpr (Q == 0 && FROM_GLOBAL) {
+            // (pre: the caller requested this row's first-stage inputs earlier - the second operand of the product, while the
+            //  first one was being transformed - and they are used where they landed)
+            if constexpr (!PRELOADED) gs_load_global<NC, 0>(x0, grow, jt, band, bandv);
+            gs_compute<NC, 0>(x0, twl, s, jt);
+            gs_store_lds<NC, 0>(x0, img + row * NC, jt);
+        } else {
+            XArr<NC, Q> x;
+            gs_load_lds<NC, Q>(x, img + row * NC, jt);
+            __syncthreads();
+            gs_compute<NC, Q>(x, twl, s, jt);
+            gs_store_lds<NC, Q>(x, img + row * NC, jt);
+        }
+        __syncthreads();
+        gen_chain_to_regs<NC, Q + 1, false>(img, grow, band, bandv, twl, s, row, jt, xl, x0);
+    } else {
+        gs_load_lds<NC, Q>(xl, img + row * NC, jt);
+        __syncthreads(); // the image is free again
+        gs_compute<NC, Q>(xl, twl, s, jt);
     }
 }
 // one image for the compile-time lengths beyond 1024 points (see gen_stage_inplace)
@@ -391,7 +625,10 @@ __global__ __launch_bounds__(kGenThreads, (((EPT <= 8 || (NC != 0 && gen_one_ima
     const cf* __restrict__ in1 = A.in1 ? reinterpret_cast<const cf*>(A.in1) + gbase + ((A.nbatch > 1) ? (size_t)bz * A.bstride_in1 : (size_t)0) : nullptr;
     const float* __restrict__ gtab = A.gtab ? A.gtab + gbase : nullptr;
     cf* const out0 = reinterpret_cast<cf*>(A.out) + zoff_out + ((MID == MID_ATOMS) ? (size_t)blockIdx.y * A.species_stride : (size_t)0);
-    if constexpr (PRE != XF_NONE || POST != XF_NONE) {
+    // round 5: the slice-loop passes of the one-image kernels chain their transforms through registers (below)
+    constexpr bool CHAIN = FDES_GEN_CHAIN && ONE && PRE != XF_NONE && POST != XF_NONE && STORE_T &&
+                           (MID == MID_GTAB || MID == MID_EXPIV_PAIR || MID == MID_MASK || MID == MID_MULPSI || MID == MID_PTAB);
+    if constexpr ((PRE != XF_NONE || POST != XF_NONE) && !CHAIN) {
         if (tw_lds) {
             const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
             cf* twd = glds + nimg * tile;
@@ -418,6 +655,105 @@ __global__ __launch_bounds__(kGenThreads, (((EPT <= 8 || (NC != 0 && gen_one_ima
                 dstl[er[i] * N + ec[i]] = dead ? cf{0.f, 0.f} : src[(unsigned)er[i] * pin + (unsigned)ec[i]];
             }
     };
+
+    // ---- round 5: the slice-loop passes of the one-image kernels with their transforms chained through registers: the first
+    // stage of the leading transform reads the rows from global memory, its last stage leaves the spectrum (resp. the real-space
+    // row) in registers, the point-wise operation works there, and the result enters the image as that stage's output
+    if constexpr (CHAIN) {
+        constexpr int NN = CT ? NC : 1280; // (CHAIN implies a compile-time length; the alternative only keeps the templates below well-formed)
+        constexpr int QL = make_fac(NN).nf - 1;
+        using SL = GStage<NN, QL>;
+        const int row = tid >> (9 - FC.lrows), jt = tid & (SL::tpr - 1);
+        const int grow = row0 + row;
+        const float sp = (PRE == XF_INV) ? -1.f : 1.f, sq = (POST == XF_INV) ? -1.f : 1.f;
+        cf* __restrict__ rowp = cur + row * NN;
+        cf xa[SL::NBT][SL::RX];
+        cf xb[(MID == MID_MULPSI) ? SL::NBT : 1][(MID == MID_MULPSI) ? SL::RX : 1];
+        float keep[(MID == MID_EXPIV_PAIR) ? SL::NBT : 1][(MID == MID_EXPIV_PAIR) ? SL::RX : 1];
+        {
+            // the rows are requested first (both operands of the product: the second one lands while the first is being
+            // transformed), the twiddle table moves into LDS behind the requests (the first stage needs no twiddle)
+            XArr<NN, 0> x0, xpre;
+            if constexpr (MID == MID_MULPSI) {
+                gs_load_global<NN, 0>(x0, in1 + (unsigned)row * pin, jt, (A.skip_dead_loads & 2) != 0, A.band);
+                if constexpr (FDES_GEN_PREFETCH_B) gs_load_global<NN, 0>(xpre, in0 + (unsigned)row * pin, jt, (A.skip_dead_loads & 1) != 0, A.band);
+            } else {
+                gs_load_global<NN, 0>(x0, in0 + (unsigned)row * pin, jt, (A.skip_dead_loads & 1) != 0, A.band);
+            }
+            if (tw_lds) {
+                const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
+                cf* twd = glds + nimg * tile;
+                for (int i = tid; i < (tw_mode == 2 ? N / 2 : N); i += kGenThreads) twd[i] = tw[i];
+            }
+            if constexpr (MID == MID_MULPSI) {
+                gen_chain_to_regs<NN, 0, true, true>(cur, nullptr, false, 0, twl, sp, row, jt, xb, x0);
+                if constexpr (FDES_GEN_PREFETCH_B) gen_chain_to_regs<NN, 0, true, true>(cur, nullptr, false, 0, twl, sp, row, jt, xa, xpre);
+                else gen_chain_to_regs<NN, 0, true>(cur, in0 + (unsigned)row * pin, (A.skip_dead_loads & 1) != 0, A.band, twl, sp, row, jt, xa, x0);
+            } else {
+                gen_chain_to_regs<NN, 0, true, true>(cur, nullptr, false, 0, twl, sp, row, jt, xa, x0);
+            }
+        }
+        const float md = (float)A.mindim;
+#pragma unroll
+        for (int b = 0; b < SL::NBT; b++) {
+            const int j = jt + b * SL::tpr;
+            if (j < SL::nb) {
+#pragma unroll
+                for (int i = 0; i < SL::RX; i++) {
+                    const int p = rdx_slot<SL::RX>(i);
+                    const int col = j + i * SL::Ns; // last stage: k = j
+                    cf v = xa[b][p];
+                    if constexpr (MID == MID_GTAB) v = v * gtab[(unsigned)row * pin + (unsigned)col];
+                    if constexpr (MID == MID_MASK) v = gen_outside(iwc(col, NN), iwc(grow, A.nrows), md) ? cf{0.f, 0.f} : v * A.scale;
+                    if constexpr (MID == MID_PTAB) {
+                        const cf pr = reinterpret_cast<const cf*>(A.prow)[grow], pc = reinterpret_cast<const cf*>(A.pcol)[col];
+                        v = gen_outside(iwc(col, NN), iwc(grow, A.nrows), md) ? cf{0.f, 0.f} : cmul3(v, cmul3(pr, pc));
+                    }
+                    if constexpr (MID == MID_MULPSI) v = cmul3(v, xb[b][p]); // f0 = t, f1 = psi
+                    if constexpr (MID == MID_EXPIV_PAIR) {
+                        keep[b][p] = v.y;
+                        float sn, cs;
+                        const float e = (A.scale == 0.f) ? 1.f : __expf(-(v.x * A.scale));
+                        if (fabsf(v.x) <= kSincosFast) sincos_cw(v.x, sn, cs);
+                        else sincos_wide(v.x, sn, cs);
+                        v = cf{e * cs, e * sn};
+                    }
+                    xa[b][p] = v;
+                }
+            }
+        }
+        auto store_t = [&](cf* outp) { // transposed grid: consecutive threads write the R consecutive elements of one output row
+            cf* __restrict__ dst = outp + row0;
+            for (int e = tid; e < tile; e += kGenThreads) {
+                const int c = e >> F.lrows, rr = e & (R - 1);
+                if (A.skip_dead_stores && dead_index(iwc(c, N), A.band)) continue;
+                dst[(unsigned)c * ldt + (unsigned)rr] = cur[rr * N + c];
+            }
+        };
+        gs_store_lds<NN, QL>(xa, rowp, jt);
+        __syncthreads();
+        gen_inplace_stages<NN, 0>(cur, twl, sq, row, jt);
+        store_t(out0);
+        if constexpr (MID == MID_EXPIV_PAIR) {
+#pragma unroll
+            for (int b = 0; b < SL::NBT; b++)
+#pragma unroll
+                for (int p = 0; p < SL::RX; p++) {
+                    const float v = keep[b][p];
+                    float sn, cs;
+                    const float e = (A.scale == 0.f) ? 1.f : __expf(-(v * A.scale));
+                    if (fabsf(v) <= kSincosFast) sincos_cw(v, sn, cs);
+                    else sincos_wide(v, sn, cs);
+                    xa[b][p] = cf{e * cs, e * sn};
+                }
+            __syncthreads(); // the first slice's tile has been read
+            gs_store_lds<NN, QL>(xa, rowp, jt);
+            __syncthreads();
+            gen_inplace_stages<NN, 0>(cur, twl, sq, row, jt);
+            store_t(reinterpret_cast<cf*>(A.out2) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_out2 : (size_t)0));
+        }
+        return;
+    }
 
     float keep_f[(MID == MID_EXPIV_PAIR) ? EPT : 1]; // second slice's potential of a pair
     if constexpr (MID == MID_GTABN) {
@@ -680,9 +1016,6 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
     f.rows = gen_rows(n);
     f.lrows = gen_lrows(f.rows);
     const int ept = (f.rows * n + kGenThreads - 1) / kGenThreads;
-#ifndef FDES_GEN_SPECIALISED
-#define FDES_GEN_SPECIALISED 1
-#endif
     if (FDES_GEN_SPECIALISED) { // the grids the reference ships (bin/dataFDES.cnf, bin/test.qsc, Si_001_11k_cnf) and a few round ones
         if (n == 320) return gdispatch<320, 8>(pre, mid, post, st_t, a, f, st);
         if (n == 800) return gdispatch<800, 8>(pre, mid, post, st_t, a, f, st);
