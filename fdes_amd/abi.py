@@ -155,6 +155,7 @@ PROTOTYPES = [
     ("fdes_comm_create", C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, _P(_vp)]),
     ("fdes_comm_destroy", C.c_int, [_vp]),
     ("fdes_plan_reduce_intensity", C.c_int, [_vp, _vp, C.c_int]),
+    ("fdes_plan_reduce_intensity_span", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     ("fdes_plan_want_exitwave", C.c_int, [_vp, C.c_int]),
     ("fdes_plan_get_exitwave", C.c_int, [_vp, _P(C.c_float)]),
     ("fdes_plan_potential", C.c_int, [_vp, C.c_int, C.c_int, _P(C.c_float)]),

@@ -315,6 +315,10 @@ class Plan:
         """Sum of the ranks' running intensity sums onto `root` through RCCL (fdes_plan_reduce_intensity); every rank calls it."""
         self._c(self.lib.fdes_plan_reduce_intensity(self.h, comm, int(root)))
 
+    def reduce_intensity_span(self, comm, root, lo, hi):
+        """The same for a measurement that spans the ranks lo .. hi only (fdes_plan_reduce_intensity_span); those ranks call it."""
+        self._c(self.lib.fdes_plan_reduce_intensity_span(self.h, comm, int(root), int(lo), int(hi)))
+
     def want_exitwave(self, on=True):
         self._c(self.lib.fdes_plan_want_exitwave(self.h, int(on)))
 

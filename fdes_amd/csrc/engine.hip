@@ -196,6 +196,8 @@ struct fdes_plan {
     bool peer_host_only = false;    // the peer copy was refused once: partial sums are staged through host memory (option "peer_copy" 0 forces it)
     std::vector<float2> peer_host;
     hipEvent_t peer_ev = nullptr;
+    float* span_stage = nullptr; size_t span_stage_n = 0; // fdes_plan_reduce_intensity_span: landing zone of the root (peers side by side)
+    float* span_send = nullptr; size_t span_send_n = 0;   // ... and what a peer sends: float view of I [+ EW]
     // timing
     std::vector<EvPair> evs;
     size_t ev_used = 0;
@@ -207,11 +209,31 @@ struct fdes_plan {
 namespace {
 
 std::once_flag g_rocfft_once;
-// Host threads driving different GPUs (or several plans on one GPU) share the process: a stream capture in one thread is
-// invalidated by synchronising runtime calls (hipMalloc, hipFree, blocking hipMemcpy) made by another thread meanwhile
-// ("operation failed due to a previous error during capture").  Captures are rare (once per empty-slice pattern) and
-// those calls only occur in plan creation / destruction, so the two are simply serialised.
-std::recursive_mutex g_capture_mutex;
+// Host threads driving different GPUs (or several plans on one GPU) share the process.  A stream capture begun in the
+// default (global / relaxed) mode is invalidated by synchronising runtime calls (hipMalloc, hipFree, blocking hipMemcpy) made
+// by ANY thread meanwhile ("operation failed due to a previous error during capture"); until round 4 one process-wide mutex
+// therefore serialised every plan creation / destruction with every capture, so that eight workers set their plans up one
+// after the other.  Round 5: the slice loop is captured in hipStreamCaptureModeThreadLocal - calls of OTHER threads, on this
+// or another device, do not touch the capture; the capturing thread's own hipMalloc (the table of a power of the propagator
+// that a run of empty slices needs) exchanges the mode for the duration of that call - and what is left is one lock PER
+// DEVICE around the capture itself and around the allocations a thread makes while another thread of the same device may be
+// capturing (FDES_CAPTURE_LOCK=0 drops even that: the test of the capture mode, tests/test_gpu_r5.py).
+struct DeviceLocks {
+    std::recursive_mutex m[65];
+    bool enabled = true;
+    DeviceLocks() { const char* e = std::getenv("FDES_CAPTURE_LOCK"); enabled = !(e && e[0] == '0'); }
+};
+DeviceLocks g_dev_locks;
+struct DeviceGuard { // lock of one device (index 64: devices beyond 63)
+    std::unique_lock<std::recursive_mutex> lk;
+    explicit DeviceGuard(int device) { if (g_dev_locks.enabled) lk = std::unique_lock<std::recursive_mutex>(g_dev_locks.m[(device >= 0 && device < 64) ? device : 64]); }
+};
+// a synchronising allocation made by a thread that may itself be capturing (thread-local capture mode forbids it otherwise)
+struct RelaxCapture {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    RelaxCapture() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
+    ~RelaxCapture() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
+};
 
 // Live handles.  Every entry point that destroys checks its handle here first, so destroying twice, destroying a plan
 // after its context, or a finaliser that runs after the at-exit sweep below are refused (FDES_EINVAL) instead of
@@ -330,7 +352,7 @@ int empty_query(fdes_plan* pl, int n, const int* ks, const int* js)
     const int cap = pl->gang > 1 ? pl->gang : 1;
     if (n > cap) return FDES_EINVAL;
     if (!pl->qs) {
-        std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // allocations vs a capture in another thread
+        DeviceGuard guard(c->device); // stream creation vs a capture in another thread of this device
         int least = 0, greatest = 0;
         HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(c, hipStreamCreateWithPriority(&pl->qs, hipStreamNonBlocking, greatest)); // a queue of its own, ahead of the lanes' kernels
@@ -539,7 +561,10 @@ int propagator_pow(fdes_plan* pl, int n, float2** out)
         for (auto& e : *pl->capture_pow)
             if (e.first == n) { *out = e.second; return FDES_OK; }
         float2* t = nullptr;
-        RC(dmalloc(c, &t, len));
+        {
+            RelaxCapture relax; // hipMalloc from the capturing thread
+            RC(dmalloc(c, &t, len));
+        }
         pl->capture_pow->push_back({n, t});
         HIPCHK(c, k_build_propagator_1d(t, t + pl->p.m1, pl->kp, n, c->stream));
         *out = t;
@@ -547,7 +572,7 @@ int propagator_pow(fdes_plan* pl, int n, float2** out)
     }
     for (auto& e : pl->pow_tabs)
         if (e.n == n) { e.used = ++pl->pow_tick; *out = e.tab; return FDES_OK; }
-    std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc
+    DeviceGuard guard(c->device); // hipMalloc vs a capture in another thread of this device
     float2* tab = nullptr;
     if (pl->pow_tabs.size() >= 16) {
         size_t lru = 0;
@@ -864,12 +889,12 @@ int slice_loop(fdes_plan* pl, int nslices)
     fdes_plan::LoopGraph* gr = nullptr;
     for (auto& e : pl->graphs) if (e.key == key && e.pattern == pattern) gr = &e;
     if (!gr) {
-        std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
+        DeviceGuard guard(c->device);
         const int64_t skipped0 = pl->slices_skipped;
         std::vector<std::pair<int, float2*>> pow_owned;
         pl->capture_pow = &pow_owned;
         pl->capturing = true;
-        hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
+        hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
         int rc = FDES_OK;
         if (e == hipSuccess) rc = issue();
         hipGraph_t graph = nullptr;
@@ -1455,8 +1480,8 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
 int fdes_plan_destroy(fdes_plan* pl)
 {
     if (!pl || !live_plan(pl)) return FDES_EINVAL;
-    std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
     fdes_ctx* c = pl->ctx;
+    DeviceGuard guard(c->device);
     { std::lock_guard<std::mutex> g(g_live_mutex); g_live_plan.erase(pl); }
     c->plans.erase(std::remove(c->plans.begin(), c->plans.end(), pl), c->plans.end());
     (void)hipSetDevice(c->device);
@@ -1468,7 +1493,7 @@ int fdes_plan_destroy(fdes_plan* pl)
     void* ptrs[] = {pl->Z_d, pl->spec_d, pl->xyz0_d, pl->xyzTO_d, pl->xyzK_d, pl->xyzFP_d, pl->dwf_d, pl->occ_d, pl->bins.keys,
                     pl->bins.keys_sorted, pl->bins.vals, pl->bins.order, pl->bins.seg, pl->bins.tmp, pl->bins.recs, pl->bins.recs_sorted, pl->bins.rowstart, pl->D, pl->VH, pl->T, pl->PSI,
                     pl->P, pl->I, pl->EW, pl->J, pl->scal, pl->A == pl->C ? nullptr : pl->A, pl->C, pl->C2, pl->E, pl->PSIH,
-                    pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT, pl->peer_stage, pl->real_send}; // F aliases C
+                    pl->tables_shared ? nullptr : pl->PT, pl->tables_shared ? nullptr : pl->GT, pl->peer_stage, pl->real_send, pl->span_stage, pl->span_send}; // F aliases C
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (void* q : pl->gang_owned) if (q) (void)hipFree(q);
     pl->gang_owned = {}; pl->gbins = {}; pl->gseg = {}; pl->gq = {};
@@ -1500,7 +1525,9 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
 {
     if (!live_ctx(c) || !out) return FDES_EINVAL;
     *out = nullptr;
-    std::lock_guard<std::recursive_mutex> guard(g_capture_mutex);
+    // (no lock: with thread-local captures the allocations below disturb nobody, and the workers of fdes_build_measurements_multi
+    //  create their plans at the same time; g_plan_create_overlap counts creations that ran side by side - the harness under
+    //  tests/host_cpp/ asserts on it)
     RC(check_params(c, p_in, a));
     HIPCHK(c, hipSetDevice(c->device));
     fdes_plan* pl = new fdes_plan();
@@ -1998,7 +2025,7 @@ int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src)
     if (!same) {
         // the intensity sum travels as its real view (I.y is identically zero): half the bytes over xGMI
         if (!src->real_send) {
-            std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc vs a capture in another thread
+            DeviceGuard guard(sc->device); // hipMalloc vs a capture in another thread of that device
             RC(dmalloc(sc, &src->real_send, src->m12));
         }
         HIPCHK(sc, k_real_pack(src->real_send, src->I, src->m12, sc->stream));
@@ -2009,7 +2036,7 @@ int fdes_plan_accumulate_from(fdes_plan* dst, fdes_plan* src)
     RC(fold_lanes(dst));
     HIPCHK(dc, hipStreamWaitEvent(dc->stream, src->peer_ev, 0));
     if (!same && !dst->peer_stage) {
-        std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc vs a capture in another thread
+        DeviceGuard guard(dc->device); // hipMalloc vs a capture in another thread of that device
         RC(dmalloc(dc, &dst->peer_stage, dst->m12));
     }
     const int nsum = (dst->want_ew && src->want_ew) ? 2 : 1;
@@ -2057,6 +2084,10 @@ struct Rccl {
     int (*CommInitRank)(void**, int, fdes_comm_id, int) = nullptr; // ncclUniqueId is passed BY VALUE: a 128-byte struct
     int (*CommDestroy)(void*) = nullptr;
     int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl& rccl()
@@ -2074,7 +2105,11 @@ Rccl& rccl()
         *(void**)(&r.CommDestroy) = dlsym(r.so, "ncclCommDestroy");
         *(void**)(&r.Reduce) = dlsym(r.so, "ncclReduce");
         *(void**)(&r.GetErrorString) = dlsym(r.so, "ncclGetErrorString");
-        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Reduce && r.GetErrorString;
+        *(void**)(&r.Send) = dlsym(r.so, "ncclSend");
+        *(void**)(&r.Recv) = dlsym(r.so, "ncclRecv");
+        *(void**)(&r.GroupStart) = dlsym(r.so, "ncclGroupStart");
+        *(void**)(&r.GroupEnd) = dlsym(r.so, "ncclGroupEnd");
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Reduce && r.GetErrorString && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
     });
     return r;
 }
@@ -2131,7 +2166,7 @@ int fdes_plan_reduce_intensity(fdes_plan* pl, fdes_comm* k, int root)
     HIPCHK(c, hipSetDevice(c->device));
     RC(fold_lanes(pl));
     if (!pl->real_send || (k->rank == root && !pl->peer_stage)) {
-        std::lock_guard<std::recursive_mutex> guard(g_capture_mutex); // hipMalloc vs a capture in another thread
+        DeviceGuard guard(c->device); // hipMalloc vs a capture in another thread of this device
         if (!pl->real_send) RC(dmalloc(c, &pl->real_send, pl->m12));
         if (k->rank == root && !pl->peer_stage) RC(dmalloc(c, &pl->peer_stage, pl->m12));
     }
@@ -2143,6 +2178,59 @@ int fdes_plan_reduce_intensity(fdes_plan* pl, fdes_comm* k, int root)
     if (pl->want_ew) { // the coherent exit-wave sum of print_level 2 (src/crystalMaker.cu:347, 370) is complex: 2 m12 floats, in place
         const int e2 = r.Reduce(pl->EW, pl->EW, 2 * pl->m12, /* ncclFloat32 */ 7, /* ncclSum */ 0, root, k->comm, c->stream);
         if (e2 != 0) { c->err = std::string("ncclReduce (exit wave): ") + r.GetErrorString(e2); return FDES_EGPU; }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDES_OK;
+}
+
+// The same sum for a measurement whose configurations sit on the ranks lo .. hi of the communicator only (a series dealt over
+// the GPUs: most measurements span two or three of them): no collective - the ranks outside the span take no part - but one
+// group of point-to-point transfers, every rank of the span sending the float view of its sum (and its exit-wave sum) to
+// `root`, which receives them side by side (each peer has an xGMI link of its own to the root) and adds them in rank order,
+// so that the result does not depend on arrival order.
+int fdes_plan_reduce_intensity_span(fdes_plan* pl, fdes_comm* k, int root, int lo, int hi)
+{
+    if (!live_plan(pl) || !k || !k->comm || lo < 0 || hi >= k->nranks || lo > hi || root < lo || root > hi || k->rank < lo || k->rank > hi || pl->ctx != k->ctx)
+        return FDES_EINVAL;
+    if (lo == 0 && hi == k->nranks - 1) return fdes_plan_reduce_intensity(pl, k, root);
+    fdes_ctx* c = pl->ctx;
+    Rccl& r = rccl();
+    HIPCHK(c, hipSetDevice(c->device));
+    RC(fold_lanes(pl));
+    const size_t m12 = pl->m12, per = pl->want_ew ? 3 * m12 : m12; // floats per peer: intensity view [+ complex exit wave]
+    const int npeer = hi - lo; // senders
+    if (k->rank == root) {
+        if (pl->span_stage_n < (size_t)npeer * per) {
+            DeviceGuard guard(c->device);
+            if (pl->span_stage) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(pl->span_stage); pl->span_stage = nullptr; }
+            RC(dmalloc(c, &pl->span_stage, (size_t)npeer * per));
+            pl->span_stage_n = (size_t)npeer * per;
+        }
+        int e = r.GroupStart();
+        int slot = 0;
+        for (int q = lo; q <= hi && e == 0; q++) {
+            if (q == root) continue;
+            e = r.Recv(pl->span_stage + (size_t)slot * per, per, /* ncclFloat32 */ 7, q, k->comm, c->stream);
+            slot++;
+        }
+        const int e2 = r.GroupEnd();
+        if (e != 0 || e2 != 0) { c->err = std::string("ncclRecv: ") + r.GetErrorString(e ? e : e2); return FDES_EGPU; }
+        for (int i = 0; i < npeer; i++) { // fixed association order: ascending rank
+            const float* part = pl->span_stage + (size_t)i * per;
+            HIPCHK(c, k_axpy_real(pl->I, part, m12, c->stream));
+            if (pl->want_ew) HIPCHK(c, k_axpy(pl->EW, reinterpret_cast<const float2*>(part + m12), m12, 1.f, c->stream));
+        }
+    } else {
+        if (pl->span_send_n < per) {
+            DeviceGuard guard(c->device);
+            if (pl->span_send) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(pl->span_send); pl->span_send = nullptr; }
+            RC(dmalloc(c, &pl->span_send, per));
+            pl->span_send_n = per;
+        }
+        HIPCHK(c, k_real_pack(pl->span_send, pl->I, m12, c->stream));
+        if (pl->want_ew) HIPCHK(c, hipMemcpyAsync(pl->span_send + m12, pl->EW, sizeof(float2) * m12, hipMemcpyDeviceToDevice, c->stream));
+        const int e = r.Send(pl->span_send, per, /* ncclFloat32 */ 7, root, k->comm, c->stream);
+        if (e != 0) { c->err = std::string("ncclSend: ") + r.GetErrorString(e); return FDES_EGPU; }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FDES_OK;

@@ -22,7 +22,9 @@ int Fft2D::pick_wg(int m1, int m2)
 }
 bool Fft2D::lds_supported(int m1, int m2) { return pick_wg(m1, m2) != 0; }
 
-static int upload_twiddles(int n, float2** tw0, float2** tw1, std::string* err)
+// (asynchronous copies on the plan's stream + a wait for that stream: a blocking hipMemcpy goes through the device's legacy
+//  stream and is refused - and invalidates the capture - while another host thread captures a slice loop on this device)
+static int upload_twiddles(int n, float2** tw0, float2** tw1, hipStream_t st, std::string* err)
 {
     const bool gen = gen_pass_supported_len(n); // mixed-radix passes: tw0 = the n roots of unity, tw1 unused
     const int T = n / 16, P = T / 16 > 0 ? T / 16 : 1;
@@ -30,8 +32,9 @@ static int upload_twiddles(int n, float2** tw0, float2** tw1, std::string* err)
     if (gen) gen_pass_twiddles(n, h0.data());
     else lds_fft_twiddles(n, h0.data(), h1.data());
     if (hipMalloc((void**)tw0, h0.size() * sizeof(float)) != hipSuccess || hipMalloc((void**)tw1, h1.size() * sizeof(float)) != hipSuccess ||
-        hipMemcpy(*tw0, h0.data(), h0.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(*tw1, h1.data(), h1.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpyAsync(*tw0, h0.data(), h0.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(*tw1, h1.data(), h1.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
         if (err) *err = "twiddle upload failed";
         return -1;
     }
@@ -47,8 +50,8 @@ int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err)
     backend = (opt == 1 || !lds_ok) ? 1 : 2;
     if (backend == 2) {
         wg = pick_wg(m1, m2);
-        if (upload_twiddles(m1, &tw0x, &tw1x, err)) return -1;
-        if (upload_twiddles(m2, &tw0y, &tw1y, err)) return -1;
+        if (upload_twiddles(m1, &tw0x, &tw1x, st, err)) return -1;
+        if (upload_twiddles(m2, &tw0y, &tw1y, st, err)) return -1;
         if (hipMalloc((void**)&scratch, sizeof(float2) * (size_t)m1 * m2) != hipSuccess) { if (err) *err = "scratch allocation failed"; return -1; }
         return 0;
     }

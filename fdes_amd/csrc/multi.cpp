@@ -8,11 +8,13 @@
 //     2 s) of the span adds the sum of the GPU at offset i + s: log2(GPUs) rounds of concurrent peer copies over xGMI (the
 //     intensity as its float view, 16 MiB at 2048^2) and add kernels instead of seven serial rounds through the owner; the
 //     association order is fixed by the tree, so the images do not depend on timing;
-//   * FDES_REDUCE=rccl: ONE ncclReduce(sum, float[m1 m2]) to the owner over a communicator created once per
-//     call, for measurements that span ALL GPUs (the frozen-phonon configurations of one image dealt over the node) when
-//     every worker has a device of its own (the exit-wave sum of print_level 2 rides along as a second reduce); anything
-//     else, and any failure to set the communicator up, takes the tree.  Not the default: creating a communicator costs more than a whole headline job
-//     (seconds against tens of milliseconds), and RCCL picks the association order.
+//   * FDES_REDUCE=rccl: over a communicator created once per call, when every worker has a device of its own: ONE
+//     ncclReduce(sum, float[m1 m2]) to the owner for a measurement that spans ALL GPUs (the frozen-phonon
+//     configurations of one image dealt over the node; the exit-wave sum of print_level 2 rides along as a second reduce), one
+//     group of ncclSend / ncclRecv to the owner for a measurement that spans only some of them (round 5:
+//     fdes_plan_reduce_intensity_span - the ranks outside the span take no part); any failure to set the communicator up
+//     takes the tree.  Not the default: creating a communicator costs more than a whole headline job (seconds against tens
+//     of milliseconds), and in the collective RCCL picks the association order.
 // The potential output (print_level > 0) does not depend on (k, j): its slices are dealt over the GPUs.  Random numbers are
 // keyed on (k, j): the images do not depend on the partition beyond the association order of that one sum.
 #include <atomic>
@@ -94,9 +96,9 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
         bool distinct = true;
         for (int r = 0; r < ngpu; r++)
             for (int q = 0; q < r; q++) distinct = distinct && devices[r] != devices[q];
-        bool spans_all = false;
-        for (int k = 0; k < n3; k++) spans_all = spans_all || (first[(size_t)k] == 0 && last[(size_t)k] == ngpu - 1);
-        want_rccl = mode && !std::strcmp(mode, "rccl") && distinct && spans_all && fdes_comm_unique_id(&comm_id) == FDES_OK;
+        bool any_split = false;
+        for (int k = 0; k < n3; k++) any_split = any_split || last[(size_t)k] > first[(size_t)k];
+        want_rccl = mode && !std::strcmp(mode, "rccl") && distinct && any_split && fdes_comm_unique_id(&comm_id) == FDES_OK;
     }
     std::vector<fdes_comm*> comms((size_t)ngpu, nullptr);
     std::atomic<int> comm_failures{0};
@@ -139,12 +141,13 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
                 rc = fdes_plan_begin_measurement(pl, k);
                 for (int i = jlo; i < jhi && rc == FDES_OK; i++) rc = fdes_plan_run_config(pl, k, i % count, weight);
             }
-            if (split && rccl && first[(size_t)k] == 0 && last[(size_t)k] == ngpu - 1) {
-                // one collective; a rank that has failed must not leave the others inside it: all agree first
+            if (split && rccl) {
+                // one collective (span = every GPU) or one group of sends to the owner (a shorter span: only its ranks take
+                // part); a rank that has failed must not leave the others inside either: ALL workers agree first
                 if (rc != FDES_OK) failed_before_collective[(size_t)k]++;
                 bar.wait();
-                if (failed_before_collective[(size_t)k].load() == 0) rc = fdes_plan_reduce_intensity(pl, comms[(size_t)r], first[(size_t)k]);
-                else if (rc == FDES_OK) rc = FDES_EGPU; // a peer failed
+                if (failed_before_collective[(size_t)k].load() != 0) { if (rc == FDES_OK) rc = FDES_EGPU; } // a peer failed
+                else if (in_span) rc = fdes_plan_reduce_intensity_span(pl, comms[(size_t)r], first[(size_t)k], first[(size_t)k], last[(size_t)k]);
             } else if (split) { // every thread passes every barrier, whatever its state, so that nobody waits for ever
                 if (rc != FDES_OK) plans[(size_t)r] = nullptr;
                 const int f = first[(size_t)k], n = last[(size_t)k] - f + 1, i = r - f;

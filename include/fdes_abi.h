@@ -210,6 +210,11 @@ int fdes_comm_unique_id(fdes_comm_id* id);
 int fdes_comm_create(fdes_ctx* ctx, int nranks, int rank, const fdes_comm_id* id, fdes_comm** comm);
 int fdes_comm_destroy(fdes_comm* comm);
 int fdes_plan_reduce_intensity(fdes_plan* plan, fdes_comm* comm, int root);
+/* The same sum for a measurement whose configurations sit on the ranks lo .. hi (lo <= root <= hi) of the communicator only:
+ * ONLY those ranks call it, in the same order for the same measurement; every rank of the span sends the float view of its
+ * sum (and its exit-wave sum) to `root` in one group of point-to-point transfers (ncclSend / ncclRecv: every peer has an
+ * xGMI link of its own to the root), the root adds them in rank order.  A span of the whole communicator is the collective above. */
+int fdes_plan_reduce_intensity_span(fdes_plan* plan, fdes_comm* comm, int root, int lo, int hi);
 /* Coherent exit-wave average (print_level > 1, src/crystalMaker.cu:347,370): switch the accumulation on before
  * fdes_plan_begin_measurement; fdes_plan_get_exitwave copies the sum of the current measurement, float[2*m1*m2]. */
 int fdes_plan_want_exitwave(fdes_plan* plan, int on);

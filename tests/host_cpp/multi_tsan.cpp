@@ -4,8 +4,11 @@
 // stores and NO locking, so any pair of calls that the driver's barriers fail to order shows up as a data race.  The
 // result is also compared with the serial sum (partition + ownership logic).
 // Build + run: tests/test_host_cpu.py::test_multi_gpu_driver_under_thread_sanitizer
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <map>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -41,6 +44,22 @@ struct StubWorld {
     }
 };
 static StubWorld g_world;
+// rendezvous of the ranks lo .. hi of a span (fdes_plan_reduce_intensity_span): only they take part
+static std::mutex g_span_m;
+static std::map<std::pair<int, int>, StubWorld*> g_span_worlds;
+static StubWorld& span_world(int lo, int hi, int nranks)
+{
+    std::lock_guard<std::mutex> g(g_span_m);
+    StubWorld*& w = g_span_worlds[{lo, hi}];
+    if (!w) { w = new StubWorld; w->n = hi - lo + 1; w->slot.assign((size_t)nranks, nullptr); }
+    return *w;
+}
+static int g_span_calls = 0; // (written by the roots under g_span_m)
+// plan creation of the workers must overlap in time (round 5: no process-wide lock in front of fdes_plan_create): the stub
+// takes 40 ms and records when it ran
+static std::mutex g_create_m;
+static std::vector<std::pair<double, double>> g_create_times;
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct fdes_comm { int nranks, rank; };
 static int g_reduce_calls = 0; // (written by rank 0 only)
 
@@ -53,6 +72,9 @@ const char* fdes_last_error(const fdes_ctx*) { return "stub"; }
 int fdes_build_measurements(fdes_ctx*, const fdes_params*, const fdes_atoms*, float*, float*, float*) { return FDES_EUNSUPPORTED; }
 int fdes_plan_create(fdes_ctx* c, const fdes_params* p, const fdes_atoms*, fdes_plan** out)
 {
+    const double t0 = now_ms();
+    std::this_thread::sleep_for(std::chrono::milliseconds(40));
+    { std::lock_guard<std::mutex> g(g_create_m); g_create_times.push_back({t0, now_ms()}); }
     fdes_plan* pl = new fdes_plan();
     pl->ctx = c; pl->n1 = p->n1; pl->n2 = p->n2; pl->n3 = p->n3; pl->m3 = p->m3; pl->count = p->frPh > 0 ? p->frPh : 1;
     pl->m12 = (size_t)p->m1 * p->m2;
@@ -107,6 +129,27 @@ int fdes_plan_reduce_intensity(fdes_plan* pl, fdes_comm* c, int root)
     g_world.wait();
     return rc;
 }
+int fdes_plan_reduce_intensity_span(fdes_plan* pl, fdes_comm* c, int root, int lo, int hi)
+{
+    if (lo == 0 && hi == c->nranks - 1) return fdes_plan_reduce_intensity(pl, c, root);
+    if (c->rank < lo || c->rank > hi || root < lo || root > hi) return FDES_EINVAL;
+    StubWorld& w = span_world(lo, hi, c->nranks);
+    w.slot[(size_t)c->rank] = pl;
+    w.wait();
+    int rc = FDES_OK;
+    if (c->rank == root) {
+        { std::lock_guard<std::mutex> g(g_span_m); g_span_calls++; }
+        for (int r = lo; r <= hi; r++) {
+            const fdes_plan* s = w.slot[(size_t)r];
+            if (r == root) continue;
+            if (s->cur_k != pl->cur_k) rc = FDES_EINVAL; // every rank of the span must hold the same measurement
+            for (size_t i = 0; i < pl->I.size(); i += 2) pl->I[i] += s->I[i];
+            if (pl->want_ew) for (size_t i = 0; i < pl->EW.size(); i++) pl->EW[i] += s->EW[i];
+        }
+    }
+    w.wait();
+    return rc;
+}
 int fdes_plan_get_exitwave(fdes_plan* pl, float* ew) { std::memcpy(ew, pl->EW.data(), sizeof(float) * pl->EW.size()); return FDES_OK; }
 int fdes_plan_end_measurement(fdes_plan* pl, int k)
 {
@@ -139,6 +182,9 @@ static int run_case(int ngpu, int n3, int count, bool fail_one, bool rccl = fals
 {
     if (rccl) setenv("FDES_REDUCE", "rccl", 1); else unsetenv("FDES_REDUCE");
     const int reduce_calls_before = g_reduce_calls;
+    int span_calls_before = 0;
+    { std::lock_guard<std::mutex> g(g_span_m); span_calls_before = g_span_calls; }
+    { std::lock_guard<std::mutex> g(g_create_m); g_create_times.clear(); }
     fdes_params p;
     std::memset(&p, 0, sizeof p);
     p.n1 = 6; p.n2 = 5; p.m1 = 8; p.m2 = 8; p.n3 = n3; p.m3 = 7; p.frPh = count > 1 ? count : 0;
@@ -152,6 +198,24 @@ static int run_case(int ngpu, int n3, int count, bool fail_one, bool rccl = fals
     if (fail_one) return rc == FDES_OK ? 1 : 0; // must report the failure and must not hang
     if (rc != FDES_OK) return 1;
     if (rccl && n3 == 1 && count >= ngpu && g_reduce_calls != reduce_calls_before + 1) return 1; // the collective path was taken
+    {   // every worker's plan creation ran while the others' did: the latest start lies before the earliest end
+        std::lock_guard<std::mutex> g(g_create_m);
+        if ((int)g_create_times.size() != ngpu) return 1;
+        double latest_start = 0, earliest_end = 1e300;
+        for (auto& t : g_create_times) { if (t.first > latest_start) latest_start = t.first; if (t.second < earliest_end) earliest_end = t.second; }
+        if (ngpu > 1 && !(latest_start < earliest_end)) { std::printf("plan creations did not overlap\n"); return 1; }
+    }
+    if (rccl) { // measurements that span some but not all GPUs went through the span reduction, never through the tree
+        int spans = 0;
+        for (int k = 0; k < n3; k++) {
+            const int cntk = count > 1 ? count : 1, total = n3 * cntk;
+            auto rank_of = [&](int i) { const int base = total / ngpu, rem = total % ngpu; int lo = 0; for (int r = 0; r < ngpu; r++) { const int n = base + (r < rem ? 1 : 0); if (i < lo + n) return r; lo += n; } return ngpu - 1; };
+            const int f = rank_of(k * cntk), l = rank_of(k * cntk + cntk - 1);
+            if (l > f && !(f == 0 && l == ngpu - 1)) spans++;
+        }
+        std::lock_guard<std::mutex> g(g_span_m);
+        if (g_span_calls != span_calls_before + spans) { std::printf("span reductions: %d, expected %d\n", g_span_calls - span_calls_before, spans); return 1; }
+    }
     const int cnt = count > 1 ? count : 1;
     const float w = 1.f / (float)cnt;
     int bad = 0;

@@ -33,6 +33,8 @@ def test_rccl_reduce_with_one_rank():
         for j in range(4):
             pl.run_config(0, j, 0.25)
         pl.reduce_intensity(comm, 0)   # (+ the coherent exit-wave sum: a second reduce)
+        with pytest.raises(fdes_amd.FdesError):
+            pl.reduce_intensity_span(comm, 0, 0, 1)   # (round 5) a span beyond the communicator is refused, not sent
         ew = pl.get_exitwave()
         pl.end_measurement(0)
         img = pl.get_images()
