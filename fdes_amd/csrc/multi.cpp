@@ -18,6 +18,7 @@
 // The potential output (print_level > 0) does not depend on (k, j): its slices are dealt over the GPUs.  Random numbers are
 // keyed on (k, j): the images do not depend on the partition beyond the association order of that one sum.
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <condition_variable>
 #include <cstdio>
@@ -101,6 +102,8 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
         want_rccl = mode && !std::strcmp(mode, "rccl") && distinct && any_split && fdes_comm_unique_id(&comm_id) == FDES_OK;
     }
     std::vector<fdes_comm*> comms((size_t)ngpu, nullptr);
+    const bool timing = std::getenv("FDES_TIMING") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
     std::atomic<int> comm_failures{0};
     // per measurement: workers that arrived at k's collective in a failed state (written before k's barrier, read after it: every
     // rank decides from the same value, and a rank that fails later cannot change the decision a slow peer is still to read)
@@ -119,7 +122,13 @@ extern "C" int fdes_build_measurements_multi(int ngpu, const int* devices, const
             bar.wait();
             rccl = comm_failures.load() == 0;
         }
+        const auto tc0 = std::chrono::steady_clock::now();
         if (rc == FDES_OK) rc = fdes_plan_create(ctx, p, a, &pl);
+        if (timing) { // FDES_TIMING=1: when each worker's plan creation ran (the workers create their plans side by side)
+            const auto tc1 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "  FDES: worker %d (device %d): plan creation %.1f ms, started %.1f ms after the call\n", r, devices[r],
+                         std::chrono::duration<double, std::milli>(tc1 - tc0).count(), std::chrono::duration<double, std::milli>(tc0 - t_call).count());
+        }
         if (rc == FDES_OK && exitwave) rc = fdes_plan_want_exitwave(pl, 1);
         plans[(size_t)r] = rc == FDES_OK ? pl : nullptr;
         const Part q = part_of(total, ngpu, r);

@@ -15,6 +15,8 @@ import pytest
 import fdes_amd
 from tests import specimens as S
 
+from tests.conftest import full_only
+
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -318,6 +320,7 @@ def test_c2_si001_1024(engine, oracle):
     check(out, r64, r32, 2e-5, "C2 Si[001] 1024^2 x 64 slices image")
 
 
+@full_only   # (tests/test_gpu_r2.py::test_c4_full_series runs the whole series)
 def test_c4_beam_tilt_series_reduced(engine, oracle):
     """BASELINE config 4 with the series cut to 2 x 2 beam tilts x 2 frozen-phonon configurations and half the
     thickness (SrTiO3 9x9x10 cells, 1024^2 wave, 20 slices): beam tilt + Tukey window + band limit on the way in,
@@ -532,9 +535,12 @@ def test_c3_headline_size_single_configuration(oracle):
         eng = fdes_amd.Engine(0, skip_empty=skip)
         outs[skip] = eng.build_measurements(hp, at)["image"]
         eng.close()
-    r32 = oracle.build_measurements(hp, at, prec="f32")["image"]
     r64 = oracle.build_measurements(hp, at, prec="f64")["image"]
-    e32 = relerr(r32, r64)
+    # E(cpu_f32): the float32 oracle's own distance from the truth is a property of the oracle and the specimen (1.84e-5 in every
+    # run of rounds 2-5); the default suite uses that recorded value, FDES_GPU_SUITE=full recomputes it (20 s of CPU time)
+    e32 = 1.84e-5
+    if os.environ.get("FDES_GPU_SUITE") == "full":
+        e32 = relerr(oracle.build_measurements(hp, at, prec="f32")["image"], r64)
     for skip in (0, 1):
         e = relerr(outs[skip], r64)
         print(f"[parity] C3 2048^2 x 256 slices, skip_empty={skip}: E(gpu)={e:.3e} E(cpu_f32)={e32:.3e}")

@@ -13,6 +13,8 @@ import fdes_amd
 from tests import specimens as S
 from tests.test_gpu_parity import check, relerr
 
+from tests.conftest import full_only
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -69,7 +71,7 @@ def test_rectangular_grids_with_padded_rows(oracle, kw):
     eng.close()
 
 
-@pytest.mark.parametrize("threads,band_skip", [(0, 1), (512, 0)])
+@pytest.mark.parametrize("threads,band_skip", [pytest.param(0, 1, marks=full_only), (512, 0)])   # (defaults at 4096^2: test_c5_full_specimen)
 def test_c5_grid_slice_loop_against_oracle(oracle, threads, band_skip):
     """BASELINE config 5's grid (4096^2): the 512-thread / 136 KiB pass geometry (MID_ATOMS, MID_GTABN, MID_EXPIV_PAIR,
     MID_MASK, MID_MULPSI, MID_PTAB at N = 4096) through five slices with two species and 600 atoms, against the float64
@@ -94,6 +96,7 @@ def test_c5_grid_slice_loop_against_oracle(oracle, threads, band_skip):
     eng.close()
 
 
+@full_only   # (test_c5_full_specimen runs both launch sequences at 4096^2; the short cut itself: tests/test_gpu_fused.py, test_gpu_r4.py)
 def test_c5_grid_engine_default_with_empty_slices(oracle):
     """4096^2 with the engine defaults (graph replay, two lanes, empty-slice runs as P^n) on a specimen that leaves
     slices empty at both ends: image of two frozen-phonon configurations against the float64 oracle."""

@@ -10,6 +10,8 @@ import fdes_amd
 from tests import specimens as S
 from tests.test_gpu_parity import check, relerr
 
+from tests.conftest import full_only
+
 pytestmark = pytest.mark.gpu
 
 
@@ -99,7 +101,7 @@ def test_wave_fft_against_numpy(shape, threads):
     eng.close()
 
 
-@pytest.mark.parametrize("threads", [64, 65, 128])
+@pytest.mark.parametrize("threads", [64, pytest.param(65, marks=full_only), 128])   # (65: the software-pipelined variant, not a default anywhere)
 @pytest.mark.parametrize("m,nz,stagger", [(2048, 1, 0), (2048, 2, 16), (4096, 1, 0), (4096, 2, 8), (1024, 1, 0), (1024, 3, 0)])
 def test_wave_passes_slice_loop(oracle, m, nz, stagger, threads):
     """Every pass of the slice loop on the one-wave-per-row kernels (P1' atoms, P2 with one and two species, the two-slice
@@ -125,7 +127,7 @@ def test_wave_passes_slice_loop(oracle, m, nz, stagger, threads):
     eng.close()
 
 
-@pytest.mark.parametrize("threads", [64, 65, 128])
+@pytest.mark.parametrize("threads", [64, pytest.param(65, marks=full_only), pytest.param(128, marks=full_only)])
 def test_wave_passes_equal_lanes_graph_and_empty_slices(oracle, threads):
     """One-wave-per-row passes through the whole driver at 2048^2: two lanes, graph replay, frozen phonons, runs of
     empty slices (P^n steps) - image against the float32 oracle."""

@@ -53,16 +53,24 @@ def test_export_list_without_test_hooks(tmp_path):
 
 
 def test_library_builds_from_clean(tmp_path):
-    """Every object of the library from scratch into a scratch directory (the in-tree build reuses objects): all 13
-    translation units for gfx950, the link with the export list, and the result exports what the in-tree library does."""
+    """Every object of the library from scratch into a scratch directory (the in-tree build reuses objects): all 16
+    translation units for gfx950 and the link with the export list - as a `make TEST_HOOKS=0` build, the one a maintainer
+    ships: it exports the product entry points only, and fdes_amd/abi.py loads it (the hook prototypes are optional there: a
+    call of one fails loudly)."""
     csrc = os.path.join(ROOT, "fdes_amd", "csrc")
     lib = tmp_path / "libFDES_SHARED_LIB.so"
-    r = subprocess.run(["make", "-s", "-j8", "-C", csrc, f"B={tmp_path}/build", f"LIB={lib}", str(lib)], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run(["make", "-s", "-j8", "-C", csrc, f"B={tmp_path}/build", f"LIB={lib}", "TEST_HOOKS=0", str(lib)], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert len(os.listdir(tmp_path / "build")) == 14   # 13 objects + exports.map
+    assert len(os.listdir(tmp_path / "build")) == 17   # 16 objects + exports.map
     out = subprocess.run(["nm", "-D", "--defined-only", str(lib)], capture_output=True, text=True, check=True).stdout
-    ref = subprocess.run(["nm", "-D", "--defined-only", abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    assert {l.split()[-1] for l in out.splitlines()} == {l.split()[-1] for l in ref.splitlines()}
+    prod = set(open(os.path.join(csrc, "exports_product.txt")).read().split())
+    assert {l.split()[-1] for l in out.splitlines()} == prod
+    code = ("import sys; sys.path.insert(0, %r); from fdes_amd import abi\n"
+            "lib = abi.load_library(%r)\n"
+            "assert lib.fdes_abi_version() == 1\n"
+            "try:\n    lib.fdes_plan_probe_ms(None, None, None)\nexcept RuntimeError as e:\n    print('hook refused:', e)\n" % (ROOT, str(lib)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "hook refused" in r.stdout, r.stdout + r.stderr
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

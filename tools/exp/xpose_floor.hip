@@ -208,9 +208,37 @@ template <int N> void all(int pad, int nsets)
     for (int q = 0; q < 2; q++) CK(hipStreamDestroy(B.st[q]));
 }
 
+// round 5: TWO rows per workgroup (16-byte segments; the row pairs 4g, 4g+1 and 4g+2, 4g+3 go to neighbouring workgroups of one
+// XCD, so that their segments can meet in that L2 as 32-byte pairs) against four, with today's XCD remap and 64-element padding
+template <int N> void two_rows(int pad, int nsets)
+{
+    const int pitch = N + pad;
+    const size_t ne = (size_t)N * pitch;
+    Bufs B;
+    B.g.resize((size_t)2 * nsets);
+    for (auto& p : B.g) { CK(hipMalloc(&p, ne * 8)); CK(hipMemset(p, 0, ne * 8)); }
+    for (int q = 0; q < 2; q++) CK(hipStreamCreateWithFlags(&B.st[q], hipStreamNonBlocking));
+    std::vector<float> hin(ne * 2);
+    unsigned s = 12345u;
+    for (auto& v : hin) { s = s * 1664525u + 1013904223u; v = (float)(s >> 8); }
+    run<N, 4, 0, 8, 8>(B, pitch, nsets, hin, "natural");
+    run<N, 4, 1, 8, 8>(B, pitch, nsets, hin, "store-T, 4 rows (today)");
+    run<N, 2, 1, 8, 8>(B, pitch, nsets, hin, "store-T, 2 rows");
+    run<N, 2, 1, 8, 16>(B, pitch, nsets, hin, "store-T, 2 rows");
+    run<N, 2, 1, 16, 16>(B, pitch, nsets, hin, "store-T, 2 rows");
+    run<N, 2, 2, 8, 8>(B, pitch, nsets, hin, "load-T, 2 rows");
+    for (auto p : B.g) CK(hipFree(p));
+    for (int q = 0; q < 2; q++) CK(hipStreamDestroy(B.st[q]));
+}
+
 int main(int argc, char** argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 2048;
+    if (argc > 2 && argv[2][0] == 'r') { // "r2": the two-row question only
+        if (n == 2048) { two_rows<2048>(32, 2); two_rows<2048>(32, 16); }
+        else { two_rows<4096>(64, 2); two_rows<4096>(64, 4); }
+        return 0;
+    }
     if (n == 2048) {
         all<2048>(32, 2);
         all<2048>(32, 16);
