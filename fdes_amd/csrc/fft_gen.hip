@@ -110,6 +110,13 @@ __host__ __device__ constexpr bool factorize(int n, GenFac& f)
     }
     return true;
 }
+// Round 5 (FDES_GEN_T1024): the compile-time lengths beyond 2048 points as FOUR-row tiles with 1024 threads - one workgroup per
+// CU with the sixteen waves that two 512-thread workgroups of two rows have, but 32-byte segments in the transposed store (a
+// bare transposing copy at 4096^2 takes 81 us with two rows per workgroup against 50 us with four: profiles/r05_xpose_floor_two_rows.txt)
+// and the twiddle table copied once per four rows
+#ifndef FDES_GEN_T1024
+#define FDES_GEN_T1024 0
+#endif
 #ifndef FDES_GEN_ROWS4
 #define FDES_GEN_ROWS4 0 // experiment: four-row tiles (32-byte segments, one workgroup per CU) for the specialised lengths beyond 2048 points
 #endif
@@ -121,7 +128,11 @@ __host__ __device__ constexpr bool gen_specialised(int n)
     return n == 320 || n == 800 || n == 1000 || n == 400 || n == 500 || n == 640 || n == 1280 || n == 1600 || n == 2000 || n == 2560 || n == 3000 ||
            n == 3072 || n == 3200 || n == 3600 || n == 4000;
 }
-__host__ __device__ constexpr int gen_rows(int n) { return n > 2048 ? ((FDES_GEN_ROWS4 && gen_specialised(n)) ? 4 : 2) : (n > 512 ? 4 : 8); }
+__host__ __device__ constexpr int gen_rows(int n) { return n > 2048 ? (((FDES_GEN_ROWS4 || FDES_GEN_T1024) && gen_specialised(n)) ? 4 : 2) : (n > 512 ? 4 : 8); }
+constexpr int kGenThreads = 512; // threads of a workgroup (gen_threads below: 1024 for the four-row tiles of FDES_GEN_T1024)
+__host__ __device__ constexpr bool gen_t1024(int n) { return FDES_GEN_T1024 && n > 2048 && gen_specialised(n); }
+__host__ __device__ constexpr int gen_threads(int n) { return gen_t1024(n) ? 1024 : kGenThreads; }
+__host__ __device__ constexpr int gen_lthreads(int n) { return gen_t1024(n) ? 10 : 9; }
 __host__ __device__ constexpr int gen_lrows(int rows) { return rows == 2 ? 1 : (rows == 4 ? 2 : 3); }
 // rows beyond 2048 points: the tile images fill the LDS, the twiddle table is read from global memory
 __host__ __device__ constexpr bool gen_tw_in_lds(int n) { return n <= 2048; }
@@ -137,7 +148,7 @@ __host__ __device__ constexpr GenFac make_fac(int n)
 
 // 512 threads = 8 waves per workgroup (two workgroups per CU at 1000 points: 2 waves per SIMD hide the LDS round trips
 // of the stages); a row belongs to 512 / rows consecutive threads
-constexpr int kGenThreads = 512;
+
 
 // s = +1 forward, -1 inverse: multiply by -i (forward) / +i (inverse)
 __device__ __forceinline__ cf mi_s(cf a, float s) { return cf{a.y * s, -a.x * s}; }
@@ -280,8 +291,9 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
 __host__ __device__ constexpr int gen_tw_mode(int n, int rows, bool one_image)
 {
     if (!one_image) return n <= 2048 ? 1 : 0;
-    if (sizeof(float) * 2 * ((size_t)rows * n + n) + 64 <= (size_t)FDES_GEN_TW_LDS_LIMIT) return 1;
-    if (n % 2 == 0 && sizeof(float) * 2 * ((size_t)rows * n + n / 2) + 64 <= (size_t)FDES_GEN_TW_LDS_LIMIT) return 2;
+    const size_t limit = gen_t1024(n) ? (size_t)160 * 1024 : (size_t)FDES_GEN_TW_LDS_LIMIT; // (the four-row tiles are alone on their CU)
+    if (sizeof(float) * 2 * ((size_t)rows * n + n) + 64 <= limit) return 1;
+    if (n % 2 == 0 && sizeof(float) * 2 * ((size_t)rows * n + n / 2) + 64 <= limit) return 2;
     return 0;
 }
 
@@ -403,7 +415,7 @@ template <int NC, int Q> struct GStage {
     static constexpr GenFac F = make_fac(NC);
     static constexpr int RX = F.radix[Q], nb = F.nbf[Q], Ns = F.ns[Q], tws = F.tws[Q];
     static constexpr unsigned magic = F.magic[Q];
-    static constexpr int tpr = kGenThreads >> F.lrows;
+    static constexpr int tpr = gen_threads(NC) >> F.lrows;
     static constexpr int NBT = (nb + tpr - 1) / tpr;
     static constexpr bool half_tw = gen_tw_mode(NC, F.rows, true) == 2;
     static constexpr bool last = Q + 1 == F.nf;
@@ -543,7 +555,7 @@ template <bool CT, bool ONE = false, int NCI = 320>
 __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restrict__ twl, const GenFac& F, const bool inverse)
 {
     const float s = inverse ? -1.f : 1.f;
-    const int tpr = kGenThreads >> F.lrows, row = (int)threadIdx.x / tpr, jt = (int)threadIdx.x - row * tpr; // tpr is a power of two
+    const int tpr = (CT ? gen_threads(NCI) : kGenThreads) >> F.lrows, row = (int)threadIdx.x / tpr, jt = (int)threadIdx.x - row * tpr; // tpr is a power of two
     if constexpr (ONE) {
         gen_inplace_stages<NCI, 0>(cur, twl, s, row, jt);
         return;
@@ -587,13 +599,14 @@ __device__ __forceinline__ bool gen_outside(int i1, int i2, float md) { return (
 // (the reference's shipped grids 320, 800, 1000: the generic kernel spends ten times the vector instructions per point
 // of the power-of-two kernels on stage bookkeeping and index arithmetic)
 template <int NC, int EPT, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(kGenThreads, (((EPT <= 8 || (NC != 0 && gen_one_image(NC))) && MID != MID_GTABN) ? 4 : 2)) void k_gpass(PassArgs A, GenFac Frt) // EPT <= 8 (rows up to 1024 points): two workgroups per CU (the species loop of MID_GTABN needs more than 128 registers)
+__global__ __launch_bounds__(gen_threads(NC), (((EPT <= 8 || (NC != 0 && gen_one_image(NC))) && MID != MID_GTABN) ? 4 : 2)) void k_gpass(PassArgs A, GenFac Frt) // EPT <= 8 (rows up to 1024 points): two workgroups per CU (the species loop of MID_GTABN needs more than 128 registers)
 {
     constexpr bool CT = NC != 0;
     constexpr GenFac FC = make_fac(CT ? NC : 320);
     const GenFac F = CT ? FC : Frt;
     extern __shared__ cf glds[];
     const int N = F.n, R = F.rows, tid = threadIdx.x;
+    constexpr int THR = gen_threads(NC), LTHR = gen_lthreads(NC);
     const int tile = R * N;
     constexpr bool ONE = CT && gen_one_image(NC);
     cf* cur = glds;
@@ -632,14 +645,14 @@ __global__ __launch_bounds__(kGenThreads, (((EPT <= 8 || (NC != 0 && gen_one_ima
         if (tw_lds) {
             const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
             cf* twd = glds + nimg * tile;
-            for (int i = tid; i < (tw_mode == 2 ? N / 2 : N); i += kGenThreads) twd[i] = tw[i];
+            for (int i = tid; i < (tw_mode == 2 ? N / 2 : N); i += THR) twd[i] = tw[i];
         }
     }
     // this thread's elements: columns jt + tpr i of ONE row (the 512 / R threads of a row are consecutive: their loads of a
     // row are contiguous, and row and column need no arithmetic per element); EPT >= N / tpr = R N / 512
     int er[EPT], ec[EPT];
     {
-        const int tpr = kGenThreads >> F.lrows, r = tid >> (9 - F.lrows), c = tid & (tpr - 1);
+        const int tpr = THR >> F.lrows, r = tid >> (LTHR - F.lrows), c = tid & (tpr - 1);
 #pragma unroll
         for (int i = 0; i < EPT; i++) {
             er[i] = r;
@@ -663,7 +676,7 @@ __global__ __launch_bounds__(kGenThreads, (((EPT <= 8 || (NC != 0 && gen_one_ima
         constexpr int NN = CT ? NC : 1280; // (CHAIN implies a compile-time length; the alternative only keeps the templates below well-formed)
         constexpr int QL = make_fac(NN).nf - 1;
         using SL = GStage<NN, QL>;
-        const int row = tid >> (9 - FC.lrows), jt = tid & (SL::tpr - 1);
+        const int row = tid >> (LTHR - FC.lrows), jt = tid & (SL::tpr - 1);
         const int grow = row0 + row;
         const float sp = (PRE == XF_INV) ? -1.f : 1.f, sq = (POST == XF_INV) ? -1.f : 1.f;
         cf* __restrict__ rowp = cur + row * NN;
@@ -683,7 +696,7 @@ __global__ __launch_bounds__(kGenThreads, (((EPT <= 8 || (NC != 0 && gen_one_ima
             if (tw_lds) {
                 const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
                 cf* twd = glds + nimg * tile;
-                for (int i = tid; i < (tw_mode == 2 ? N / 2 : N); i += kGenThreads) twd[i] = tw[i];
+                for (int i = tid; i < (tw_mode == 2 ? N / 2 : N); i += THR) twd[i] = tw[i];
             }
             if constexpr (MID == MID_MULPSI) {
                 gen_chain_to_regs<NN, 0, true, true>(cur, nullptr, false, 0, twl, sp, row, jt, xb, x0);
@@ -724,7 +737,7 @@ __global__ __launch_bounds__(kGenThreads, (((EPT <= 8 || (NC != 0 && gen_one_ima
         }
         auto store_t = [&](cf* outp) { // transposed grid: consecutive threads write the R consecutive elements of one output row
             cf* __restrict__ dst = outp + row0;
-            for (int e = tid; e < tile; e += kGenThreads) {
+            for (int e = tid; e < tile; e += THR) {
                 const int c = e >> F.lrows, rr = e & (R - 1);
                 if (A.skip_dead_stores && dead_index(iwc(c, N), A.band)) continue;
                 dst[(unsigned)c * ldt + (unsigned)rr] = cur[rr * N + c];
@@ -800,11 +813,11 @@ __global__ __launch_bounds__(kGenThreads, (((EPT <= 8 || (NC != 0 && gen_one_ima
             }
             if (phi[0] - plo[0] + phi[1] - plo[1] == 0) { // workgroup-uniform: the spectrum of an empty row group is zero
                 if constexpr (STORE_T) {
-                    for (int e = tid; e < tile; e += kGenThreads) (out0 + row0)[(unsigned)(e >> F.lrows) * ldt + (unsigned)(e & (R - 1))] = cf{0.f, 0.f};
+                    for (int e = tid; e < tile; e += THR) (out0 + row0)[(unsigned)(e >> F.lrows) * ldt + (unsigned)(e & (R - 1))] = cf{0.f, 0.f};
                 }
                 return;
             }
-            for (int e = tid; e < tile; e += kGenThreads) cur[e] = cf{0.f, 0.f};
+            for (int e = tid; e < tile; e += THR) cur[e] = cf{0.f, 0.f};
             __syncthreads();
             if (tid < 64) {
                 float* ldsf = reinterpret_cast<float*>(cur);
@@ -895,7 +908,7 @@ __global__ __launch_bounds__(kGenThreads, (((EPT <= 8 || (NC != 0 && gen_one_ima
         } else {
             // transposed grid: N rows of length ldt; consecutive threads write the R consecutive elements of one output row
             cf* __restrict__ dst = outp + row0;
-            for (int e = tid; e < tile; e += kGenThreads) {
+            for (int e = tid; e < tile; e += THR) {
                 const int c = e >> F.lrows, rr = e & (R - 1);
                 if (A.skip_dead_stores && dead_index(iwc(c, N), A.band)) continue;
                 dst[(unsigned)c * ldt + (unsigned)rr] = cur[rr * N + c];
@@ -959,10 +972,10 @@ template <int NC, int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaun
     const int nz = a.nbatch > 1 ? a.nbatch : 1;
     if (a.ev_start && a.ev_stop) {
         w.ev_start = w.ev_stop = nullptr;
-        hipExtLaunchKernelGGL(kern, dim3(groups, ny, nz), dim3(kGenThreads), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w, f);
+        hipExtLaunchKernelGGL(kern, dim3(groups, ny, nz), dim3(gen_threads(NC)), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w, f);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(groups, ny, nz), dim3(kGenThreads), lds_bytes, st, w, f);
+    hipLaunchKernelGGL(kern, dim3(groups, ny, nz), dim3(gen_threads(NC)), lds_bytes, st, w, f);
     return hipGetLastError();
 }
 

@@ -3,7 +3,7 @@
 half-size LDS regions: FDES_W_HALFX=12 build of fft_wave.hip, FDES_LIB selects it) against the defaults.
 Mean launch time [us] alone / on two streams.  Run on the GPU box."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fdes_amd
 for wg in (512, 64):
     eng = fdes_amd.Engine(0, pass_threads=wg, bench_band=1, bench_pitch=64)  # (P2 runs over all rows: bench_band is reset for it below)

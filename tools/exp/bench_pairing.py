@@ -2,7 +2,7 @@
 """Two streams: does it matter WHICH kernels run side by side?  Time for 100 launches of X on stream 0 and 100 of Y on
 stream 1 (concurrently), for same-kernel and mixed pairs; 2048^2, band flags as in the slice loop."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fdes_amd
 eng = fdes_amd.Engine(0)
 eng.set_option("pass_threads", 256)

@@ -4,7 +4,7 @@ segments) against EIGHT (pass_threads = 128: one workgroup per CU, 64-byte segme
 mean launch time [us] alone / on two streams, dense operands in cache and (cold) 8 buffer sets.  Run on the GPU box."""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fdes_amd
 
 PASSES = {"copy T": (0, 0, 0, 1), "FFT T": (1, 0, 0, 1), "P2 gtab": (1, 2, 2, 1), "P3 pair": (2, 12, 1, 1), "P4 mask": (1, 4, 2, 1),

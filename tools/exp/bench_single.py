@@ -3,7 +3,7 @@
 one-lane slice loop - single stream + hipGraph (split = 0), two-stream split loop (batch = 0), batched potential chain
 (batch = 2 / 4 / 8) - with and without the empty-slice short cut.  Run on the GPU box."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import fdes_amd
 from tests import specimens as S

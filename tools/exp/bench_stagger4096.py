@@ -2,7 +2,7 @@
 """4096-point passes: 512 threads (one workgroup per CU) against 256 threads (two per CU) with the second workgroup of a CU
 started late (stagger, units of 64 cycles), alone / on two streams.  Run on the GPU box."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fdes_amd
 PASSES = {"copy T": (0, 0, 0, 1), "FFT T": (1, 0, 0, 1), "P4 mask": (1, 4, 2, 1), "P5 mulpsi": (2, 5, 1, 1), "P6 ptab": (1, 6, 2, 1), "P3 pair": (2, 12, 1, 1)}
 BAND = {4: 1, 6: 1, 5: 6, 12: 4}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does one launch over twice the rows (a batch of two configurations) beat two launches / two streams?"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fdes_amd
 eng = fdes_amd.Engine(0)
 eng.set_option("pass_threads", 256)

@@ -2,7 +2,7 @@
 """1024-point passes (one wave per row) over the rows of 1, 2, 4 configurations in one launch, on 1 - 3 streams:
 us per configuration.  Run on the GPU box."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fdes_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 eng = fdes_amd.Engine(0)

@@ -3,7 +3,7 @@
 look-ahead, two waves per SIMD) against one row group per workgroup (pass_threads = 64), 2048-point rows, pass by pass:
 us per launch alone / on two streams.  FDES_LIB selects the build.  Run on the GPU box."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fdes_amd
 PASSES = {"copy T": (0, 0, 0, 1), "P2 gtab": (1, 2, 2, 1), "P3 pair": (2, 12, 1, 1), "P4 mask": (1, 4, 2, 1), "P5 mulpsi": (2, 5, 1, 1), "P6 ptab": (1, 6, 2, 1)}
 BAND = {4: 1, 6: 1, 5: 6, 12: 4}

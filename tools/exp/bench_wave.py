@@ -3,7 +3,7 @@
 mean launch time [us] on one and two streams, and a sweep of the staggered start.  Run on the GPU box."""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fdes_amd
 
 PASSES = {"copy T": (0, 0, 0, 1), "FFT T": (1, 0, 0, 1), "P2 gtab": (1, 2, 2, 1), "P3 pair": (2, 12, 1, 1), "P4 mask": (1, 4, 2, 1),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does a padded row pitch (not a power of two) help the transposed stores?  us per launch, 1 and 2 streams."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fdes_amd
 eng = fdes_amd.Engine(0)
 PASSES = {"copy nat": (0, 0, 0, 0), "copy T": (0, 0, 0, 1), "FFT T": (1, 0, 0, 1), "P4": (1, 4, 2, 1), "P5": (2, 5, 1, 1), "P6": (1, 6, 2, 1)}
