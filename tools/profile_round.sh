@@ -4,7 +4,7 @@
 #   PMC traffic and SQ counters (one run per counter group, never combined with tracing domains other than the kernel
 #   trace) for 2048^2 and 4096^2.            usage: tools/profile_round.sh r02
 set -e
-R=${1:-r04}
+R=${1:-r05}
 O=$PWD/gpurun_out/prof_$R
 mkdir -p $O
 export TMPDIR=/tmp
