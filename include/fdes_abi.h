@@ -279,7 +279,9 @@ int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
  *   "deterministic"  1 (default): the deposit of the rocFFT slice loop and of the potential output adds the atoms in sorted
  *                order through LDS (bit-reproducible, like the fused loop); 0: global float atomics as the reference's
  *                squareAtoms_d (src/crystalMaker.cu:100-119)
- *   "stagger"    0 (default) .. 1024: one-wave-per-row passes start the waves of a CU that many x 64 cycles apart
+ *   "stagger"    0 (default) .. 1024: one-wave-per-row passes start the waves of a CU that many x 64 cycles apart;
+ *                -1 .. -2048 (experiment, round 5): the first generation of workgroups on the odd CUs starts |value| x 64
+ *                cycles late (the CUs of the chip in different phases; measured without effect, profiles/r05_cu_class_stagger_4096.txt)
  *   "peer_copy"  1 (default): fdes_plan_accumulate_from moves a partial sum between GPUs by a peer copy and falls back
  *                to host staging when the runtime refuses it; 0: always stage through host memory                 */
 int fdes_set_option(fdes_ctx* ctx, const char* key, int64_t value);

@@ -54,7 +54,9 @@ int fdes_fft2d_host(fdes_ctx* ctx, float* data, int m1, int m2, int inverse, int
 int fdes_bench_pass(fdes_ctx* ctx, int n, int pre, int mid, int post, int store_t, int iters, int streams, double* us);
 
 /* Engine options for tests and benches only (fdes_set_option):
- *   "probe_stride"  n > 0: bracket every n-th launch of the dominant kernel with HIP events (fdes_plan_probe_ms)
+ *   "probe_stride"  n > 0: bracket every n-th launch of the probed pass class with the start / stop events of the dispatch
+ *                   itself (fdes_plan_probe_ms); a library built with TEST_HOOKS=0 refuses these keys (FDES_EINVAL)
+ *   "probe_pass"    1 .. 6: the pass class of the fused slice loop that is bracketed (1 = P1' ... 6 = P6, default 5 = P5)
  *   "lanes_active"  n > 0: run_config deals only to the first n lanes from now on (0: all)
  *   "bench_band", "bench_alt", "bench_tall", "bench_pitch", "bench_serial"  shape fdes_bench_pass only */
 

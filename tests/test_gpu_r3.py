@@ -247,7 +247,8 @@ def test_multi_gpu_driver_host_staged_fallback():
 # ------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("kw", [dict(m=256, m3=11, nz=2, nat=200, tilt=True), dict(m=512, m3=7, nz=1, nat=300, zfrac=0.2),
-                                dict(m=1024, m3=9, nz=2, nat=300, mode=2), dict(m=800, m3=6, nz=2, nat=200, zfrac=0.3)])
+                                dict(m=1024, m3=9, nz=2, nat=300, mode=2), dict(m=800, m3=6, nz=2, nat=200, zfrac=0.3),
+                                dict(m=1280, m3=5, nz=1, nat=200, zfrac=0.3)])   # (1280: the register-chained mixed-radix kernels of round 5 with grid.z batches)
 def test_batched_potential_chain_does_not_change_a_bit(oracle, kw):
     """A single image (one configuration, one lane): the potential / transmission passes of several slice pairs as one
     launch each (grid.z), the wave's passes one batch behind.  Same kernels, same operands: the exit wave is bit-identical
