@@ -48,6 +48,9 @@ struct GenFac {
 #ifndef FDES_GEN_CHAIN
 #define FDES_GEN_CHAIN 1
 #endif
+#ifndef FDES_GEN_NT_ABOVE
+#define FDES_GEN_NT_ABOVE 2048 // measured: 3000^2 +7 % with non-temporal row loads; 2000^2 and 1280^2: see profiles/r05_nt_loads.txt
+#endif
 #ifndef FDES_GEN_PREFETCH_B
 #define FDES_GEN_PREFETCH_B 1 // product pass of the chained kernels: both operands requested before the first transform
 #endif
@@ -458,7 +461,7 @@ template <int NC, int Q> __device__ __forceinline__ void gs_load_global(XArr<NC,
             for (int i = 0; i < S::RX; i++) {
                 const int c = j + i * S::nb;
                 const bool dead = band && dead_index(iwc(c, NC), bandv);
-                x[b][i] = dead ? cf{0.f, 0.f} : grow[c];
+                x[b][i] = dead ? cf{0.f, 0.f} : row_load<(NC > FDES_GEN_NT_ABOVE ? 1 << 20 : 0)>(grow + c); // (non-temporal for the lengths beyond FDES_GEN_NT_ABOVE: fft_dev.inc)
             }
         }
     }

@@ -252,9 +252,6 @@ constexpr int pass_waves(int mid) { return (mid == MID_MULPSI || mid == MID_GTAB
 #ifndef FDES_PSEP_LATE
 #define FDES_PSEP_LATE 1
 #endif
-#ifndef FDES_NT_LOADS
-#define FDES_NT_LOADS 0
-#endif
 #ifndef FDES_P5_PREFETCH
 #define FDES_P5_PREFETCH 0 // requesting the second operand with the first: measured, no gain (A/B 12.1k vs 12.1k), 14 more VGPRs
 #endif
@@ -271,15 +268,7 @@ __device__ __forceinline__ void load_rows(float2 (&a)[WGeo<WG>::NRV][16], const 
     // one 32-bit add serves the GS loads whose immediates fit the instruction's 12 bits.
     constexpr int GS = 4095 / (T * 8) + 1;
     const char* __restrict__ sb = reinterpret_cast<const char*>(src);
-    // FDES_NT_LOADS (experiment, round 5): the rows are read once - as non-temporal loads they should not push the half-written
-    // lines of the transposed store out of the XCD's L2 before the neighbouring workgroup's segment has arrived
-    auto at = [&](unsigned off, int imm) -> float2 {
-#if FDES_NT_LOADS
-        return __builtin_nontemporal_load(reinterpret_cast<const float2*>(sb + off + imm));
-#else
-        return *reinterpret_cast<const float2*>(sb + off + imm);
-#endif
-    };
+    auto at = [&](unsigned off, int imm) -> float2 { return row_load<N>(reinterpret_cast<const float2*>(sb + off + imm)); }; // (non-temporal from FDES_NT_MIN points on: fft_dev.inc)
 #pragma unroll
     for (int h = 0; h < WGeo<WG>::NRV; h++) {
         const unsigned b0 = (rbase[h] + (unsigned)t) * 8u;

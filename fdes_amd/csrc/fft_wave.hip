@@ -291,7 +291,7 @@ template <int N> __device__ __forceinline__ void wload_row(cf (&a)[N / 64], cons
     constexpr int P = N / 64, LB = N / 3;
     const char* __restrict__ sb = reinterpret_cast<const char*>(row);
     const unsigned b0 = (unsigned)t * 8u;
-    auto at = [&](unsigned off, int imm) -> cf { return *reinterpret_cast<const cf*>(sb + off + imm); };
+    auto at = [&](unsigned off, int imm) -> cf { return row_load<N>(reinterpret_cast<const cf*>(sb + off + imm)); }; // (non-temporal from FDES_NT_MIN points on: fft_dev.inc)
 #pragma unroll
     for (int l = 0; l < P; l++) {
         const int lo = 64 * l, hi = 64 * l + 63;
