@@ -51,13 +51,16 @@ struct GenFac {
 #ifndef FDES_GEN_NT_ABOVE
 #define FDES_GEN_NT_ABOVE 2048 // measured: 3000^2 +7 % with non-temporal row loads; 2000^2 and 1280^2: see profiles/r05_nt_loads.txt
 #endif
+#ifndef FDES_GEN_REV
+#define FDES_GEN_REV 1 // trailing transform of a chained pass in reversed stage order, fed from registers
+#endif
 #ifndef FDES_GEN_PREFETCH_B
 #define FDES_GEN_PREFETCH_B 1 // product pass of the chained kernels: both operands requested before the first transform
 #endif
 __host__ __device__ constexpr bool gen_three_stages(int n, int (&r)[3])
 {
     switch (n) {
-    // (stage orders measured in round 5, profiles/r05_mixed_radix.txt: the ones below are the fastest of three to seven orders per length)
+    // (stage orders of 2560, 3000, 3600 and 4000 points measured in round 5, profiles/r05_mixed_radix.txt: the fastest of four to seven each)
     case 1280: r[0] = 5; r[1] = 16; r[2] = 16; return true;
     case 1600: r[0] = 5; r[1] = 16; r[2] = 20; return true;
     case 2000: r[0] = 5; r[1] = 20; r[2] = 20; return true;
@@ -148,6 +151,25 @@ __host__ __device__ constexpr GenFac make_fac(int n)
     f.rows = gen_rows(n);
     f.lrows = gen_lrows(f.rows);
     return f;
+}
+// the same length with the stages in REVERSE order (round 5): the trailing transform of a chained pass starts with the radix the
+// leading one ended with, so that a thread's outputs of that last stage - element j + i N / RX of the row - are exactly the inputs
+// of its first butterfly of the trailing transform and never leave the registers
+__host__ __device__ constexpr GenFac make_fac_rev(int n)
+{
+    GenFac f = make_fac(n);
+    GenFac r = f;
+    int Ns = 1;
+    for (int q = 0; q < f.nf; q++) {
+        const int rx = f.radix[f.nf - 1 - q];
+        r.radix[q] = rx;
+        r.nbf[q] = n / rx;
+        r.ns[q] = Ns;
+        r.tws[q] = n / (Ns * rx);
+        r.magic[q] = (unsigned)(((1ull << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
+        Ns *= rx;
+    }
+    return r;
 }
 
 // 512 threads = 8 waves per workgroup (two workgroups per CU at 1000 points: 2 waves per SIMD hide the LDS round trips
@@ -415,8 +437,8 @@ template <int RX> __device__ __forceinline__ void rdx_dft(cf (&x)[RX], float s)
 // The pieces let a transform take its first stage's inputs straight from global memory (element j + i nb of a row: consecutive
 // threads read consecutive elements) and leave its last stage's outputs in registers, where the point-wise operation of the
 // pass finds them: two trips of the tile through LDS fewer per transform pair.
-template <int NC, int Q> struct GStage {
-    static constexpr GenFac F = make_fac(NC);
+template <int NC, int Q, bool REV = false> struct GStage {
+    static constexpr GenFac F = REV ? make_fac_rev(NC) : make_fac(NC);
     static constexpr int RX = F.radix[Q], nb = F.nbf[Q], Ns = F.ns[Q], tws = F.tws[Q];
     static constexpr unsigned magic = F.magic[Q];
     static constexpr int tpr = gen_threads(NC) >> F.lrows;
@@ -424,22 +446,22 @@ template <int NC, int Q> struct GStage {
     static constexpr bool half_tw = gen_tw_mode(NC, F.rows, true) == 2;
     static constexpr bool last = Q + 1 == F.nf;
 };
-template <int NC, int Q> using XArr = cf[GStage<NC, Q>::NBT][GStage<NC, Q>::RX]; // a thread's registers of stage Q
-template <int NC, int Q> __device__ __forceinline__ int gs_k(int j)
+template <int NC, int Q, bool REV = false> using XArr = cf[GStage<NC, Q, REV>::NBT][GStage<NC, Q, REV>::RX]; // a thread's registers of stage Q
+template <int NC, int Q, bool REV = false> __device__ __forceinline__ int gs_k(int j)
 {
-    using S = GStage<NC, Q>;
+    using S = GStage<NC, Q, REV>;
     return (S::Ns > 1) ? j - (int)__umulhi((unsigned)j, S::magic) * S::Ns : 0;
 }
 // column of output i of butterfly j after stage Q
-template <int NC, int Q> __device__ __forceinline__ int gs_out_col(int j, int i)
+template <int NC, int Q, bool REV = false> __device__ __forceinline__ int gs_out_col(int j, int i)
 {
-    using S = GStage<NC, Q>;
-    const int k = gs_k<NC, Q>(j);
+    using S = GStage<NC, Q, REV>;
+    const int k = gs_k<NC, Q, REV>(j);
     return (j - k) * S::RX + k + i * S::Ns;
 }
-template <int NC, int Q> __device__ __forceinline__ void gs_load_lds(XArr<NC, Q>& x, const cf* __restrict__ rowp, const int jt)
+template <int NC, int Q, bool REV = false> __device__ __forceinline__ void gs_load_lds(XArr<NC, Q, REV>& x, const cf* __restrict__ rowp, const int jt)
 {
-    using S = GStage<NC, Q>;
+    using S = GStage<NC, Q, REV>;
 #pragma unroll
     for (int b = 0; b < S::NBT; b++) {
         const int j = jt + b * S::tpr;
@@ -467,15 +489,15 @@ template <int NC, int Q> __device__ __forceinline__ void gs_load_global(XArr<NC,
         }
     }
 }
-template <int NC, int Q> __device__ __forceinline__ void gs_compute(XArr<NC, Q>& x, const cf* __restrict__ twl, const float s, const int jt)
+template <int NC, int Q, bool REV = false> __device__ __forceinline__ void gs_compute(XArr<NC, Q, REV>& x, const cf* __restrict__ twl, const float s, const int jt)
 {
-    using S = GStage<NC, Q>;
+    using S = GStage<NC, Q, REV>;
 #pragma unroll
     for (int b = 0; b < S::NBT; b++) {
         const int j = jt + b * S::tpr;
         if (j < S::nb) {
             if constexpr (S::Ns > 1) {
-                const int dk = gs_k<NC, Q>(j) * S::tws; // i k tws < N: the table index needs no reduction
+                const int dk = gs_k<NC, Q, REV>(j) * S::tws; // i k tws < N: the table index needs no reduction
 #pragma unroll
                 for (int i = 1; i < S::RX; i++) {
                     if constexpr (S::half_tw) { // the table holds W_N^m for m < N / 2 only: W_N^(m + N/2) = -W_N^m
@@ -491,14 +513,14 @@ template <int NC, int Q> __device__ __forceinline__ void gs_compute(XArr<NC, Q>&
         }
     }
 }
-template <int NC, int Q> __device__ __forceinline__ void gs_store_lds(const XArr<NC, Q>& x, cf* __restrict__ rowp, const int jt)
+template <int NC, int Q, bool REV = false> __device__ __forceinline__ void gs_store_lds(const XArr<NC, Q, REV>& x, cf* __restrict__ rowp, const int jt)
 {
-    using S = GStage<NC, Q>;
+    using S = GStage<NC, Q, REV>;
 #pragma unroll
     for (int b = 0; b < S::NBT; b++) {
         const int j = jt + b * S::tpr;
         if (j < S::nb) {
-            cf* __restrict__ out = rowp + gs_out_col<NC, Q>(j, 0);
+            cf* __restrict__ out = rowp + gs_out_col<NC, Q, REV>(j, 0);
 #pragma unroll
             for (int i = 0; i < S::RX; i++) out[i * S::Ns] = x[b][rdx_slot<S::RX>(i)];
         }
@@ -517,6 +539,30 @@ template <int NC, int Q> __device__ __forceinline__ void gen_inplace_stages(cf* 
         __syncthreads();
         gen_inplace_stages<NC, Q + 1>(img, twl, s, row, jt);
     }
+}
+// The trailing transform of a chained pass in the REVERSED stage order (make_fac_rev): stage 0 takes `x0` - the caller's registers,
+// the leading transform's last-stage outputs after the point-wise operation, renamed into butterfly-input order - stages 1 ... image
+// to image; the result is in the image in natural order.
+template <int NC, int Q> __device__ __forceinline__ void gen_rev_stages(cf* __restrict__ img, const cf* __restrict__ twl, const float s, const int row, const int jt)
+{
+    constexpr GenFac F = make_fac_rev(NC);
+    if constexpr (Q < F.nf) {
+        XArr<NC, Q, true> x;
+        gs_load_lds<NC, Q, true>(x, img + row * NC, jt);
+        __syncthreads();
+        gs_compute<NC, Q, true>(x, twl, s, jt);
+        gs_store_lds<NC, Q, true>(x, img + row * NC, jt);
+        __syncthreads();
+        gen_rev_stages<NC, Q + 1>(img, twl, s, row, jt);
+    }
+}
+template <int NC> __device__ __forceinline__ void gen_rev_from_regs(cf* __restrict__ img, const cf* __restrict__ twl, const float s, const int row, const int jt,
+                                                                    XArr<NC, 0, true>& x0)
+{
+    gs_compute<NC, 0, true>(x0, twl, s, jt);
+    gs_store_lds<NC, 0, true>(x0, img + row * NC, jt);
+    __syncthreads();
+    gen_rev_stages<NC, 1>(img, twl, s, row, jt);
 }
 // The stages Q ... nf - 2 image to image, then the last stage from the image into the caller's registers `xl` (round 5).
 // FROM_GLOBAL (Q = 0 only): the first stage reads its inputs from `grow` instead of the image (nothing of the image is read
@@ -747,9 +793,24 @@ __global__ __launch_bounds__(gen_threads(NC), (((EPT <= 8 || (NC != 0 && gen_one
                 dst[(unsigned)c * ldt + (unsigned)rr] = cur[rr * N + c];
             }
         };
-        gs_store_lds<NN, QL>(xa, rowp, jt);
-        __syncthreads();
-        gen_inplace_stages<NN, 0>(cur, twl, sq, row, jt);
+        // the trailing transform runs the stages in reverse order: its first butterfly of thread (b, jt) takes exactly the elements
+        // j + i N / RX that the leading transform's last stage left in xa[b] (output i in register rdx_slot(i)): no trip through LDS
+        auto trailing = [&]() {
+            if constexpr (FDES_GEN_REV && SL::RX != 16) { // (a first stage of radix 16 writes its outputs 32 dwords apart: 16-way bank conflicts - 1280^2 -6 %, 2560^2 -8 % measured)
+            static_assert(GStage<NN, 0, true>::RX == SL::RX && GStage<NN, 0, true>::NBT == SL::NBT && GStage<NN, 0, true>::nb == SL::nb, "reversed plan");
+            XArr<NN, 0, true> x0;
+#pragma unroll
+            for (int b = 0; b < SL::NBT; b++)
+#pragma unroll
+                for (int i = 0; i < SL::RX; i++) x0[b][i] = xa[b][rdx_slot<SL::RX>(i)];
+            gen_rev_from_regs<NN>(cur, twl, sq, row, jt, x0);
+            } else {
+            gs_store_lds<NN, QL>(xa, rowp, jt);
+            __syncthreads();
+            gen_inplace_stages<NN, 0>(cur, twl, sq, row, jt);
+            }
+        };
+        trailing();
         store_t(out0);
         if constexpr (MID == MID_EXPIV_PAIR) {
 #pragma unroll
@@ -764,9 +825,7 @@ __global__ __launch_bounds__(gen_threads(NC), (((EPT <= 8 || (NC != 0 && gen_one
                     xa[b][p] = cf{e * cs, e * sn};
                 }
             __syncthreads(); // the first slice's tile has been read
-            gs_store_lds<NN, QL>(xa, rowp, jt);
-            __syncthreads();
-            gen_inplace_stages<NN, 0>(cur, twl, sq, row, jt);
+            trailing();
             store_t(reinterpret_cast<cf*>(A.out2) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_out2 : (size_t)0));
         }
         return;
