@@ -417,7 +417,8 @@ int fdes_plan_reduce_intensity_span(fdes_plan* pl, fdes_comm* k, int root, int l
     Rccl& r = rccl();
     HIPCHK(c, hipSetDevice(c->device));
     RC(fold_lanes(pl));
-    const size_t m12 = pl->m12, per = pl->want_ew ? 3 * m12 : m12; // floats per peer: intensity view [+ complex exit wave]
+    const size_t m12 = pl->m12, ew_off = (m12 + 1) & ~(size_t)1; // (the exit wave is read as float2: an even float offset)
+    const size_t per = pl->want_ew ? ew_off + 2 * m12 : m12;      // floats per peer: intensity view [+ complex exit wave]
     const int npeer = hi - lo; // senders
     if (k->rank == root) {
         if (pl->span_stage_n < (size_t)npeer * per) {
@@ -438,7 +439,7 @@ int fdes_plan_reduce_intensity_span(fdes_plan* pl, fdes_comm* k, int root, int l
         for (int i = 0; i < npeer; i++) { // fixed association order: ascending rank
             const float* part = pl->span_stage + (size_t)i * per;
             HIPCHK(c, k_axpy_real(pl->I, part, m12, c->stream));
-            if (pl->want_ew) HIPCHK(c, k_axpy(pl->EW, reinterpret_cast<const float2*>(part + m12), m12, 1.f, c->stream));
+            if (pl->want_ew) HIPCHK(c, k_axpy(pl->EW, reinterpret_cast<const float2*>(part + ew_off), m12, 1.f, c->stream));
         }
     } else {
         if (pl->span_send_n < per) {
@@ -448,7 +449,7 @@ int fdes_plan_reduce_intensity_span(fdes_plan* pl, fdes_comm* k, int root, int l
             pl->span_send_n = per;
         }
         HIPCHK(c, k_real_pack(pl->span_send, pl->I, m12, c->stream));
-        if (pl->want_ew) HIPCHK(c, hipMemcpyAsync(pl->span_send + m12, pl->EW, sizeof(float2) * m12, hipMemcpyDeviceToDevice, c->stream));
+        if (pl->want_ew) HIPCHK(c, hipMemcpyAsync(pl->span_send + ew_off, pl->EW, sizeof(float2) * m12, hipMemcpyDeviceToDevice, c->stream));
         const int e = r.Send(pl->span_send, per, /* ncclFloat32 */ 7, root, k->comm, c->stream);
         if (e != 0) { c->err = std::string("ncclSend: ") + r.GetErrorString(e); return FDES_EGPU; }
     }
