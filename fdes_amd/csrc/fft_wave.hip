@@ -505,7 +505,7 @@ __device__ __forceinline__ int live_cols(int i2, int md2)
 // the other, and half-size regions two (66.7 KiB each, <= 256 registers): P4 65.4 -> 53.2 us, P6 67.5 -> 54.4 us (round 4,
 // tools/bench_hx4096.py) - the default for these two passes at 4096 points, whatever kernels the other passes use.
 #ifndef FDES_W_HALFX
-#define FDES_W_HALFX 12
+#define FDES_W_HALFX 76 // 4 + 8: P4, P6 at 4096 points (round 4); 64: P1' at 4096 points (round 5: C5 +1.5 %; 16, the filter pass P2: -2 % again)
 #endif
 template <int N, int MID, bool PIPE> constexpr bool whalfx()
 {
@@ -724,6 +724,45 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
                 }
                 continue;
             }
+            if constexpr (HX) {
+                // half-size regions (4096 points, two workgroups per CU): the tile holds ONE component at a time - slice q0's
+                // deposit (real part) first, then slice q1's (imaginary part); same records, same order, same sums
+                float* const xf = reinterpret_cast<float*>(xr);
+                float* const ldsf = reinterpret_cast<float*>(lds);
+#pragma unroll 1
+                for (int comp = 0; comp < 2; comp++) {
+#pragma unroll
+                    for (int l = 0; l < P; l++) xf[t + 64 * l] = 0.f;
+                    __syncthreads();
+                    if (tid < 64) {
+#pragma unroll 1
+                        for (int base = plo[comp]; base < phi[comp]; base += 64) {
+                            const int i = base + tid;
+                            if (i < phi[comp]) {
+                                const AtomRec ar = recs[i];
+                                const float a1 = fabsf(ar.r1), a2 = fabsf(ar.r2);
+                                const int s1 = ar.r1 < 0.f ? -1 : 1, s2 = ar.r2 < 0.f ? -1 : 1;
+#pragma unroll
+                                for (int px = 0; px < 4; px++) {
+                                    const int c = ar.i1 + ((px == 2 || px == 3) ? s1 : 0);
+                                    const int rr = ar.i2 + ((px == 1 || px == 2) ? s2 : 0) - row0;
+                                    const float wgt = ((px == 2 || px == 3) ? a1 : (1 - a1)) * ((px == 1 || px == 2) ? a2 : (1 - a2)) * ar.occ;
+                                    if (rr >= 0 && rr < R && c >= 0 && c < N) atomicAdd(&ldsf[rr * G_::ROWP + c], wgt);
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (comp == 0) {
+#pragma unroll
+                        for (int l = 0; l < P; l++) a[l].x = xf[t + 64 * l];
+                    } else {
+#pragma unroll
+                        for (int l = 0; l < P; l++) a[l].y = xf[t + 64 * l];
+                    }
+                }
+                wave_fence();
+            } else {
 #pragma unroll
             for (int l = 0; l < P; l++) xr[t + 64 * l] = cf{0.f, 0.f};
             __syncthreads();
@@ -754,6 +793,7 @@ __device__ __forceinline__ void wpass_body(const PassArgs& A, cf* __restrict__ l
 #pragma unroll
             for (int l = 0; l < P; l++) a[l] = xr[t + 64 * l];
             wave_fence();
+            }
         }
         if constexpr (MID == MID_MULPSI && !PRE_B && PIPE) wload_row<N>(b, in1, t, (A.skip_dead_loads & 2) != 0);
         if constexpr (MID == MID_PTAB && !PV_HELD && !PIPE && !(HX && N > 2048)) {
