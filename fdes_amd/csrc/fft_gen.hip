@@ -60,9 +60,9 @@ struct GenFac {
 __host__ __device__ constexpr bool gen_three_stages(int n, int (&r)[3])
 {
     switch (n) {
-    // (stage orders of 2560, 3000, 3600 and 4000 points measured in round 5, profiles/r05_mixed_radix.txt: the fastest of four to seven each)
-    case 1280: r[0] = 5; r[1] = 16; r[2] = 16; return true;
-    case 1600: r[0] = 5; r[1] = 16; r[2] = 20; return true;
+    // (stage orders measured in round 5, profiles/r05_mixed_radix.txt: the fastest of four to seven per length)
+    case 1280: r[0] = 10; r[1] = 16; r[2] = 8; return true; // (5, 16, 16: -7 %)
+    case 1600: r[0] = 10; r[1] = 16; r[2] = 10; return true;
     case 2000: r[0] = 5; r[1] = 20; r[2] = 20; return true;
     case 2560: r[0] = 10; r[1] = 16; r[2] = 16; return true;
     case 3000: r[0] = 15; r[1] = 20; r[2] = 10; return true; // (15, 10, 20: -4 %; 20, 15, 10: -3 %)
