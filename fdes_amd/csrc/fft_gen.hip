@@ -595,8 +595,12 @@ __device__ __forceinline__ void gen_chain_to_regs(cf* __restrict__ img, const cf
         gs_compute<NC, Q>(xl, twl, s, jt);
     }
 }
-// one image for the compile-time lengths beyond 1024 points (see gen_stage_inplace)
-__host__ __device__ constexpr bool gen_one_image(int nc) { return nc > 1024; }
+// one image for the compile-time lengths beyond 512 points (round 4: beyond 1024)
+#ifndef FDES_GEN_ONE_ABOVE
+#define FDES_GEN_ONE_ABOVE 512 // round 5: 640, 800 and 1000 points too (with the chained transforms: 800^2 +18 %, 1000^2 +23 %; rows up to 512 points
+                               // belong to one wave each, whose stages need no workgroup barrier between two images)
+#endif
+__host__ __device__ constexpr bool gen_one_image(int nc) { return nc > FDES_GEN_ONE_ABOVE; }
 // twiddle table in LDS while the workgroup then still fits twice on a CU (80 KiB), else read from global memory
 
 // row FFTs of the whole tile; on return `cur` points at the image that holds the result (natural order)
