@@ -46,7 +46,7 @@ int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err)
     m1 = m1_;
     m2 = m2_;
     const bool lds_ok = lds_supported(m1, m2);
-    if (opt == 2 && !lds_ok) { if (err) *err = "hand-written FFT needs grid lengths 256 ... 4096 that are powers of two, or 2^a 3^b 5^c 7^d up to 4096"; return -1; }
+    if (opt == 2 && !lds_ok) { if (err) *err = "hand-written FFT needs grid lengths 256 ... 4096 that are powers of two, or 2^a 3^b 5^c 7^d 11^e 13^f up to 4096 (a multiple of the tile rows: 4, two beyond 2048 points)"; return -1; }
     backend = (opt == 1 || !lds_ok) ? 1 : 2;
     if (backend == 2) {
         wg = pick_wg(m1, m2);

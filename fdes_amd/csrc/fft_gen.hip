@@ -4,8 +4,8 @@
 // 1000-point grids (bin/dataFDES.cnf; bin/test.qsc: m = 2 nx, src/rwQsc.cu:943-948; ExampleSpecimens/Si_001_11k_cnf).
 // The kernels of fft_lds.hip / fft_wave.hip keep a row in registers and are unrolled per power-of-two length; here the
 // same pass structure (coalesced row loads -> [row FFT] -> point-wise operation -> [row FFT] -> natural or transposed
-// store, fft_lds.h) runs with the rows in LDS and the length as a run-time value, for any N = 2^a 3^b 5^c 7^d in
-// [256, 4096]: mixed-radix Stockham stages (radices 10, 8, 7, 5, 4, 3, 2) between two LDS images of the row tile, one
+// store, fft_lds.h) runs with the rows in LDS and the length as a run-time value, for any N = 2^a 3^b 5^c 7^d 11^e 13^f in
+// [256, 4096]: mixed-radix Stockham stages (radices 13, 11, 10, 8, 7, 5, 4, 3, 2) between two LDS images of the row tile, one
 // work item per butterfly, twiddles from a table of the N-th roots of unity (double-precision values rounded once;
 // every twiddle is ONE table entry), results in natural order after the last stage.  One workgroup = R rows (8 up to
 // 512 points, 4 up to 2048, 2 beyond - two images of 2 x 4096 elements are 128 KiB, the twiddle table then stays in
@@ -24,6 +24,8 @@ namespace fdes {
 namespace {
 
 #include "fft_dev.inc"
+
+constexpr int kRxMax = 13; // largest radix of a stage: registers of one butterfly (run-time-length kernels)
 
 struct GenFac {
     int n = 0;       // row length
@@ -74,7 +76,7 @@ __host__ __device__ constexpr bool gen_three_stages(int n, int (&r)[3])
     }
 }
 
-// factors and stage tables of an n-point row; false if n has a prime factor above 7 or more than 8 stages
+// factors and stage tables of an n-point row; false if n has a prime factor above 13 or more than 8 stages
 __host__ __device__ constexpr bool factorize(int n, GenFac& f)
 {
     f.n = n;
@@ -99,8 +101,8 @@ __host__ __device__ constexpr bool factorize(int n, GenFac& f)
     }
 #endif
     // large radices first: fewer stages (each stage is one trip of the tile through LDS)
-    const int cand[7] = {10, 8, 7, 5, 4, 3, 2};
-    for (int ci = 0; ci < 7; ci++)
+    const int cand[9] = {13, 11, 10, 8, 7, 5, 4, 3, 2}; // (round 5, second half: 11 and 13, run-time-length kernels only)
+    for (int ci = 0; ci < 9; ci++)
         while (m % cand[ci] == 0 && m > 1) {
             if (f.nf == 8) return false;
             f.radix[f.nf++] = cand[ci];
@@ -184,13 +186,13 @@ __device__ __forceinline__ cf mi_s(cf a, float s) { return cf{a.y * s, -a.x * s}
 __device__ __forceinline__ cf wmul_s(cf a, cf w, float s) { return s > 0.f ? cmul_rt(a, w) : cmulc_rt(a, w); } // a w (forward) / a conj(w) (inverse)
 __device__ __forceinline__ cf rot_s(cf a, float c, float sn, float s) { return wmul_s(a, cf{c, -sn}, s); }
 
-__device__ __forceinline__ void dft2(cf (&x)[10])
+__device__ __forceinline__ void dft2(cf (&x)[kRxMax])
 {
     const cf t = x[0] - x[1];
     x[0] = x[0] + x[1];
     x[1] = t;
 }
-__device__ __forceinline__ void dft3(cf (&x)[10], float s)
+__device__ __forceinline__ void dft3(cf (&x)[kRxMax], float s)
 {
     const cf t1 = x[1] + x[2];
     const cf t2 = x[0] - t1 * 0.5f;
@@ -199,7 +201,7 @@ __device__ __forceinline__ void dft3(cf (&x)[10], float s)
     x[1] = t2 + t3;
     x[2] = t2 - t3;
 }
-__device__ __forceinline__ void dft4(cf (&x)[10], float s)
+__device__ __forceinline__ void dft4(cf (&x)[kRxMax], float s)
 {
     const cf a = x[0] + x[2], b = x[0] - x[2], c = x[1] + x[3], d = mi_s(x[1] - x[3], s);
     x[0] = a + c;
@@ -220,10 +222,10 @@ __device__ __forceinline__ void dft5_(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4, fl
     x2 = m2 + n2;
     x3 = m2 - n2;
 }
-__device__ __forceinline__ void dft5(cf (&x)[10], float s) { dft5_(x[0], x[1], x[2], x[3], x[4], s); }
+__device__ __forceinline__ void dft5(cf (&x)[kRxMax], float s) { dft5_(x[0], x[1], x[2], x[3], x[4], s); }
 // radix 7 (round 4: 7-smooth lengths such as 448, 896, 1400, 1792, 2016, 3584): the six non-trivial outputs from the three
 // symmetric sums a_j = x_j + x_(7-j) and differences b_j = x_j - x_(7-j), X_k = x_0 + sum_j a_j cos(2 pi j k / 7) -/+ i sum_j b_j sin(2 pi j k / 7)
-__device__ __forceinline__ void dft7(cf (&x)[10], float s)
+__device__ __forceinline__ void dft7(cf (&x)[kRxMax], float s)
 {
     constexpr float c1 = 0.623489801858733530f, c2 = -0.222520933956314404f, c3 = -0.900968867902419126f; // cos(2 pi j / 7)
     constexpr float s1 = 0.781831482468029809f, s2 = 0.974927912181823607f, s3 = 0.433883739117558120f;  // sin(2 pi j / 7)
@@ -240,7 +242,7 @@ __device__ __forceinline__ void dft7(cf (&x)[10], float s)
     x[2] = m2 + n2; x[5] = m2 - n2;
     x[3] = m3 + n3; x[4] = m3 - n3;
 }
-__device__ __forceinline__ void dft8(cf (&x)[10], float s)
+__device__ __forceinline__ void dft8(cf (&x)[kRxMax], float s)
 {
     // two radix-4 over the even / odd inputs, then the radix-2 level with W_8^k
     cf e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
@@ -261,7 +263,7 @@ __device__ __forceinline__ void dft8(cf (&x)[10], float s)
     x[2] = e2 + o2; x[6] = e2 - o2;
     x[3] = e3 + o3; x[7] = e3 - o3;
 }
-__device__ __forceinline__ void dft10(cf (&x)[10], float s)
+__device__ __forceinline__ void dft10(cf (&x)[kRxMax], float s)
 {
     // X[k] = E[k mod 5] + W_10^k O[k mod 5]: two radix-5 over the even / odd inputs
     cf e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], e4 = x[8], o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7], o4 = x[9];
@@ -278,6 +280,51 @@ __device__ __forceinline__ void dft10(cf (&x)[10], float s)
     x[4] = e4 + o4; x[9] = e4 - o4;
 }
 
+// radix 11 and 13 (grids such as 1100 = 2 nx of a .qsc with nx = 550, 1430, 2600, 3300: cuFFT serves any size alike,
+// src/paramStructure.cu:676-679): an odd prime P from the (P - 1) / 2 symmetric sums a_j = x_j + x_(P-j) and differences
+// b_j = x_j - x_(P-j), X_k = x_0 + sum_j a_j cos(2 pi j k / P) -/+ i sum_j b_j sin(2 pi j k / P), X_(P-k) its mirror image
+// (the form of dft7 above; cosines and sines from the double-precision constants below, rounded once)
+constexpr double kCos11[5] = {0.84125353283118116886, 0.41541501300188642553, -0.14231483827328514044, -0.65486073394528506406, -0.95949297361449738989};
+constexpr double kSin11[5] = {0.54064081745559758211, 0.90963199535451837141, 0.98982144188093273238, 0.75574957435425828377, 0.28173255684142969771};
+constexpr double kCos13[6] = {0.88545602565320989590, 0.56806474673115580251, 0.12053668025532305335, -0.35460488704253562597, -0.74851074817110109863, -0.97094181742605202716};
+constexpr double kSin13[6] = {0.46472317204376854566, 0.82298386589365639458, 0.99270887409805399280, 0.93501624268541482344, 0.66312265824079520238, 0.23931566428755776715};
+template <int P> __device__ __forceinline__ void dft_prime(cf (&x)[kRxMax], float s)
+{
+    static_assert(P == 11 || P == 13, "radix");
+    constexpr int H = (P - 1) / 2;
+    cf a[H], b[H];
+#pragma unroll
+    for (int j = 1; j <= H; j++) {
+        a[j - 1] = x[j] + x[P - j];
+        b[j - 1] = x[j] - x[P - j];
+    }
+    cf sum = x[0];
+#pragma unroll
+    for (int j = 0; j < H; j++) sum = sum + a[j];
+    cf m[H], n[H];
+#pragma unroll
+    for (int k = 1; k <= H; k++) {
+        cf mk = x[0], nk = cf{0.f, 0.f};
+#pragma unroll
+        for (int j = 1; j <= H; j++) {
+            const int q = (j * k) % P;            // angle 2 pi q / P; cos(2 pi q / P) = cos(2 pi (P - q) / P), sin changes sign
+            const int qq = q <= H ? q : P - q;
+            const float c = (float)(P == 11 ? kCos11[qq - 1] : kCos13[qq - 1]);
+            const float sn = (float)(P == 11 ? kSin11[qq - 1] : kSin13[qq - 1]) * (q <= H ? 1.f : -1.f);
+            mk = mk + a[j - 1] * c;
+            nk = nk + b[j - 1] * sn;
+        }
+        m[k - 1] = mk;
+        n[k - 1] = mi_s(nk, s);
+    }
+    x[0] = sum;
+#pragma unroll
+    for (int k = 1; k <= H; k++) {
+        x[k] = m[k - 1] + n[k - 1];
+        x[P - k] = m[k - 1] - n[k - 1];
+    }
+}
+
 // One Stockham stage of radix RX over the R rows of the tile: butterfly j of a row takes src[j + i N/RX], twiddles
 // W_N^(i k N / (Ns RX)) with k = j mod Ns, and leaves dst[(j / Ns) Ns RX + k + i Ns].  `row` / `jt` / `tpr`: this thread's
 // row, its index among the tpr threads of that row.
@@ -290,7 +337,7 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
     cf* __restrict__ drow = dst + row * N;
     for (int j = jt; j < nb; j += tpr) {
         const int k = (Ns > 1) ? j - (int)__umulhi((unsigned)j, magic) * Ns : 0;
-        cf x[10];
+        cf x[kRxMax];
 #pragma unroll
         for (int i = 0; i < RX; i++) x[i] = srow[j + i * nb];
         if (Ns > 1) {
@@ -305,6 +352,7 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
         if constexpr (RX == 7) dft7(x, s);
         if constexpr (RX == 8) dft8(x, s);
         if constexpr (RX == 10) dft10(x, s);
+        if constexpr (RX == 11 || RX == 13) dft_prime<RX>(x, s);
         cf* __restrict__ out = drow + (j - k) * RX + k;
 #pragma unroll
         for (int i = 0; i < RX; i++) out[i * Ns] = x[i];
@@ -416,7 +464,7 @@ template <int RX> __device__ __forceinline__ void rdx_dft(cf (&x)[RX], float s)
 {
     if constexpr (RX == 2 || RX == 3 || RX == 4 || RX == 5) pdft<RX, 1>(x, s);
     else if constexpr (RX == 7 || RX == 8 || RX == 10) {
-        cf t[10];
+        cf t[kRxMax];
 #pragma unroll
         for (int i = 0; i < RX; i++) t[i] = x[i];
         if constexpr (RX == 7) dft7(t, s);
@@ -623,6 +671,8 @@ __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restri
         case 5: gen_stage<5>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         case 7: gen_stage<7>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         case 8: gen_stage<8>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+        case 11: gen_stage<11>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+        case 13: gen_stage<13>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         default: gen_stage<10>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         }
         // a stage of a row touches that row only: with 64 threads per row (rows up to 512 points) a row belongs to ONE wave,

@@ -385,13 +385,13 @@ def test_dense_specimen_stops_asking_for_empty_slices(oracle):
 @pytest.mark.parametrize("kw", [dict(m=256, m3=6, nz=2, frPh=4, nat=150, tilt=True), dict(m=256, m3=4, nz=2, mode=2, nat=80),
                                 dict(m=1024, m3=5, nz=3, frPh=3, nat=300, beam_tilt=True, n3=2),
                                 dict(m=320, m3=6, nz=2, frPh=3, nat=200, tilt=True), dict(m=800, m3=4, nz=2, mode=2, nat=150),
-                                dict(m=2048, m3=4, nz=2, frPh=2, nat=300), dict(m=308, m3=4, nz=2, frPh=2, nat=150, fft=1),
+                                dict(m=2048, m3=4, nz=2, frPh=2, nat=300), dict(m=374, m3=4, nz=2, frPh=2, nat=150, fft=1),
                                 dict(m=256, m3=4, nz=2, frPh=2, nat=150, fft=1)])
 def test_fused_path_is_bit_reproducible(kw):
     """Two runs of the same simulation on the fused path give the same bits: the deposits go through single-wave LDS
     atomics in sorted order, lanes are dealt round-robin and folded in lane order, graphs replay fixed launch sequences,
     and the CBED probe norm is a fixed-order two-stage sum (round 1: float atomicAdd across blocks).  Round 3: the same
-    for the mixed-radix grids (320, 800), the one-wave-per-row passes (2048) and the rocFFT path (fft = 1, and 308 = 2^2 7 11
+    for the mixed-radix grids (320, 800), the one-wave-per-row passes (2048) and the rocFFT path (fft = 1, and 374 = 2 11 17
     which no hand-written kernel serves): its deposit now adds the atoms in sorted order through an LDS tile, and the
     potential output of print_level 1 with it."""
     kw = dict(kw)

@@ -112,7 +112,8 @@ def test_qsc_sized_grids_beyond_2048_run_the_fused_loop(oracle):
     lib = fdes_amd.load_library()
     for m in (2560, 3000, 3072, 3200, 3600, 4000):
         assert lib.fdes_grid_backend(m, m, 0) == 2, m
-    assert lib.fdes_grid_backend(3000, 3000, 1) == 1 and lib.fdes_grid_backend(2002, 2002, 0) == 1   # 2002 = 2 * 7 * 11 * 13
+    assert lib.fdes_grid_backend(3000, 3000, 1) == 1 and lib.fdes_grid_backend(2006, 2006, 0) == 1   # 2006 = 2 * 17 * 59: a prime factor above 13 leaves the hand-written loop
+    assert lib.fdes_grid_backend(2288, 2288, 0) == 2 and lib.fdes_grid_backend(1100, 1100, 0) == 2     # round 5: 2288 = 16 * 11 * 13, 1100 = 2 nx of a .qsc with nx = 550
     hp, at = S.case_tiny(m=2560, m3=3, nz=2, nat=200, frPh=2, tilt=True, rect=True)
     fdes_amd.consistent(hp)
     eng = fdes_amd.Engine(0)
