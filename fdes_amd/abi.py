@@ -180,6 +180,7 @@ PROTOTYPES = [
     ("fdes_plan_get_images", C.c_int, [_vp, _P(C.c_float)]),
     ("fdes_plan_sync", C.c_int, [_vp]),
     ("fdes_plan_fft_backend", C.c_int, [_vp]),
+    ("fdes_plan_jit_kernels", C.c_int, [_vp]),
     ("fdes_grid_backend", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("fdes_plan_lanes", C.c_int, [_vp]),
     ("fdes_plan_gang", C.c_int, [_vp]),

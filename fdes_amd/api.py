@@ -330,6 +330,10 @@ class Plan:
     def fft_backend(self):
         return int(self.lib.fdes_plan_fft_backend(self.h))
 
+    def jit_kernels(self):
+        """Grid axes whose row passes run kernels compiled for that length at plan creation (0 ... 2)."""
+        return int(self.lib.fdes_plan_jit_kernels(self.h))
+
     def lanes(self):
         return int(self.lib.fdes_plan_lanes(self.h))
 

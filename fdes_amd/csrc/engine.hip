@@ -240,6 +240,7 @@ int fdes_set_option(fdes_ctx* c, const char* key, int64_t value)
     if (!std::strcmp(key, "lanes")) { if (value < 0 || value > 8) return FDES_EINVAL; c->lanes = (int)value; return FDES_OK; }
     if (!std::strcmp(key, "deterministic")) { c->deterministic = value != 0; return FDES_OK; }
     if (!std::strcmp(key, "peer_copy")) { c->peer_copy = value != 0; return FDES_OK; }
+    if (!std::strcmp(key, "jit")) { if (value < -1 || value > 1) return FDES_EINVAL; c->jit = (int)value; return FDES_OK; }
 #if FDES_TEST_HOOKS
     // keys of bench.py's roofline probe and of the fdes_bench_pass micro-benchmark: a TEST_HOOKS=0 build does not know them
     if (!std::strcmp(key, "lanes_active")) { c->lanes_active = (int)value; return FDES_OK; }
@@ -405,12 +406,14 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     PLHIP(hipMemsetAsync(pl->EW, 0, sizeof(float2) * pl->m12, c->stream));
     PLHIP(hipMemsetAsync(pl->J, 0, sizeof(float) * (size_t)pl->p.n1 * pl->p.n2 * pl->p.n3, c->stream));
     {
-        auto key = std::make_tuple(pl->p.m1, pl->p.m2, c->opt_fft);
+        const bool jit = c->jit < 0 ? gen_jit_default_on() : c->jit != 0;
+        auto key = std::make_tuple(pl->p.m1, pl->p.m2, c->opt_fft + (jit ? 4 : 0));
         auto it = c->fft_cache.find(key);
         if (it == c->fft_cache.end()) {
             std::string ferr;
             Fft2D* f = new Fft2D();
-            if (f->create(pl->p.m1, pl->p.m2, c->opt_fft, c->stream, &ferr) != 0) {
+            DeviceGuard guard(c->device); // allocations and a module load beside a possible capture in another thread of this device
+            if (f->create(pl->p.m1, pl->p.m2, c->opt_fft, c->stream, &ferr, jit) != 0) {
                 f->destroy();
                 delete f;
                 c->err = "FFT plan: " + ferr;

@@ -141,6 +141,7 @@ int fdes_grid_backend(int m1, int m2, int fft_option)
     return (fft_option != 1 && Fft2D::lds_supported(m1, m2)) ? 2 : 1;
 }
 int fdes_plan_fft_backend(const fdes_plan* pl) { return live_plan(pl) ? pl->fft->backend : FDES_EINVAL; }
+int fdes_plan_jit_kernels(const fdes_plan* pl) { return live_plan(pl) ? ((pl->fft->backend == 2 && pl->fft->jit_x) ? 1 : 0) + ((pl->fft->backend == 2 && pl->fft->jit_y) ? 1 : 0) : FDES_EINVAL; }
 int fdes_plan_lanes(const fdes_plan* pl) { return live_plan(pl) ? (int)pl->lanes.size() + 1 : FDES_EINVAL; }
 int fdes_plan_gang(const fdes_plan* pl) { return live_plan(pl) ? pl->gang : FDES_EINVAL; }
 int fdes_plan_num_slices(const fdes_plan* pl) { return live_plan(pl) ? pl->p.m3 : FDES_EINVAL; }
@@ -592,7 +593,7 @@ int fdes_fft2d_host(fdes_ctx* c, float* data, int m1, int m2, int inverse, int b
     HIPCHK(c, hipSetDevice(c->device));
     Fft2D f;
     std::string ferr;
-    if (f.create(m1, m2, backend, c->stream, &ferr) != 0) { f.destroy(); c->err = "FFT plan: " + ferr; return FDES_EGPU; }
+    if (f.create(m1, m2, backend, c->stream, &ferr, c->jit < 0 ? gen_jit_default_on() : c->jit != 0) != 0) { f.destroy(); c->err = "FFT plan: " + ferr; return FDES_EGPU; }
     if (c->pass_threads == 64 || c->pass_threads == 65 || c->pass_threads == 128) f.wg = c->pass_threads;
     float2* d = nullptr;
     const size_t bytes = sizeof(float2) * (size_t)m1 * m2;

@@ -28,6 +28,7 @@
 #include "fdes_internal.h"
 #include "fft.h"
 #include "fft_lds.h"
+#include "gen_jit.h"
 #include "geometry.h"
 #include "kernels.h"
 
@@ -64,11 +65,12 @@ struct fdes_ctx {
     int walk = 1;         // every pass is launched in this many parts (2: a part takes half of the workgroup slots, two lanes' passes share every CU)
     int pitch_pad = -1;   // elements added to every row of the fused loop's grids; -1 auto: 32 for 2048-point rows, 64 from 4096 on
     int deterministic = 1; // the deposit of the generic (rocFFT) path and of the potential output adds the atoms in sorted order through LDS (bit-reproducible); 0: global float atomics as the reference
+    int jit = -1;         // mixed-radix grid lengths without compiled-in kernels get theirs compiled by hipRTC at plan creation (gen_jit.cpp): -1 = unless FDES_JIT=0, 0 off, 1 on
     int peer_copy = 1;    // 0: fdes_plan_accumulate_from stages partial sums through host memory instead of a peer copy (the fallback path, forced)
     int probe_stride = 0; // > 0: bracket every probe_stride-th 2-D FFT with HIP events (bench roofline)
     int probe_pass = 5;   // fused loop: the pass class that is bracketed (1 = P1' ... 6 = P6; bench.py's per-pass table)
     // plans are expensive to create: one per grid size AND requested back-end (option "fft" may change between plans)
-    std::map<std::tuple<int, int, int>, Fft2D*> fft_cache;
+    std::map<std::tuple<int, int, int>, Fft2D*> fft_cache; // (third entry: option fft + 4 * (run-time compilation asked for))
     // plans created on this context and not yet destroyed: fdes_destroy takes them down first, so a host that forgets
     // fdes_plan_destroy (or a Python finaliser that runs late) cannot leave a plan pointing at a dead context
     std::vector<fdes_plan*> plans;

@@ -26,10 +26,13 @@ struct Fft2D {
     float2 *tw0x = nullptr, *tw1x = nullptr, *tw0y = nullptr, *tw1y = nullptr;
     float2* scratch = nullptr;
     int wg = 512; // workgroup geometry of the LDS passes (PassArgs::wg)
+    // kernels compiled at run time for a mixed-radix row length without compiled-in ones (gen_jit.h; PassArgs::jit), per axis
+    const void *jit_x = nullptr, *jit_y = nullptr;
+    std::string jit_note; // why a length that could have them runs the run-time-length kernels instead
 
     static bool lds_supported(int m1, int m2);
     static int pick_wg(int m1, int m2);
-    int create(int m1, int m2, int opt, hipStream_t st, std::string* err);
+    int create(int m1, int m2, int opt, hipStream_t st, std::string* err, bool jit = false);
     hipError_t exec(float2* data, bool inverse, hipStream_t st);
     void destroy();
 };

@@ -3,9 +3,12 @@
 
 #include <rocfft/rocfft.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "fft_lds.h"
+#include "gen_jit.h"
 
 namespace fdes {
 
@@ -41,7 +44,7 @@ static int upload_twiddles(int n, float2** tw0, float2** tw1, hipStream_t st, st
     return 0;
 }
 
-int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err)
+int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err, bool jit)
 {
     m1 = m1_;
     m2 = m2_;
@@ -53,6 +56,11 @@ int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err)
         if (upload_twiddles(m1, &tw0x, &tw1x, st, err)) return -1;
         if (upload_twiddles(m2, &tw0y, &tw1y, st, err)) return -1;
         if (hipMalloc((void**)&scratch, sizeof(float2) * (size_t)m1 * m2) != hipSuccess) { if (err) *err = "scratch allocation failed"; return -1; }
+        if (jit) { // a mixed-radix length without compiled-in kernels: compile them now (or take them from the cache); failure is not an error
+            jit_x = gen_jit_prepare(m1, &jit_note);
+            jit_y = (m2 == m1) ? jit_x : gen_jit_prepare(m2, &jit_note);
+            if (!jit_note.empty() && std::getenv("FDES_JIT_VERBOSE")) std::fprintf(stderr, "  FDES: run-time-length kernels (%s)\n", jit_note.c_str());
+        }
         return 0;
     }
     const size_t lengths[2] = {(size_t)m1, (size_t)m2}; // rocFFT: lengths[0] is the fastest dimension
@@ -81,11 +89,11 @@ hipError_t Fft2D::exec(float2* data, bool inverse, hipStream_t st)
         // pass 1: rows along x (length m1, m2 rows) -> scratch[kx][y]; pass 2: rows along y -> data[ky][kx]
         const int xf = inverse ? XF_INV : XF_FWD;
         PassArgs a;
-        a.in0 = data; a.out = scratch; a.tw0 = tw0x; a.tw1 = tw1x; a.nrows = m2; a.wg = wg;
+        a.in0 = data; a.out = scratch; a.tw0 = tw0x; a.tw1 = tw1x; a.nrows = m2; a.wg = wg; a.jit = jit_x;
         hipError_t e = lds_pass(m1, xf, MID_NONE, XF_NONE, true, a, st);
         if (e != hipSuccess) return e;
         PassArgs b;
-        b.in0 = scratch; b.out = data; b.tw0 = tw0y; b.tw1 = tw1y; b.nrows = m1; b.wg = wg;
+        b.in0 = scratch; b.out = data; b.tw0 = tw0y; b.tw1 = tw1y; b.nrows = m1; b.wg = wg; b.jit = jit_y;
         return lds_pass(m2, xf, MID_NONE, XF_NONE, true, b, st);
     }
     void* in[1] = {data};

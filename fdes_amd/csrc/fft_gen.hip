@@ -12,12 +12,25 @@
 // global memory, i.e. in the caches: 64-, 32- resp. 16-byte segments in the transposed store; round 4: .qsc inputs give
 // m = 2 nx, src/rwQsc.cu:943-948, so nx = 1280 ... 2000 means 2560-, 3000-, 3072-, 3200-, 3600-, 4000-point rows).  The slice loop of the engine then runs
 // these sizes with the same 4.5 launches per slice as the power-of-two grids instead of rocFFT + point-wise kernels.
+// Run-time compilation (round 5, gen_jit.cpp): the same source compiled by hipRTC at plan creation with -DFDES_GEN_JIT_N=<length>
+// gives a length without a compiled-in kernel the compile-time form (k_gpass<NC != 0>: twice the rate of the run-time-length
+// kernels); under __HIPCC_RTC__ only the device side is compiled and the pass kernels of that ONE length are exported by name.
 #include "fft_lds.h"
 #include "geometry.h"
 
+#ifndef __HIPCC_RTC__
 #include <atomic>
 #include <cmath>
 #include <type_traits>
+
+#include "gen_jit.h"
+#else
+// hipRTC has no <type_traits>: the two tag types fft_dev.inc selects its sine / cosine range with
+namespace std {
+struct false_type { static constexpr bool value = false; };
+struct true_type { static constexpr bool value = true; };
+} // namespace std
+#endif
 
 namespace fdes {
 
@@ -76,6 +89,35 @@ __host__ __device__ constexpr bool gen_three_stages(int n, int (&r)[3])
     }
 }
 
+// n = a b c with radices the compile-time kernels have butterflies for, for a length outside the table above: the most balanced
+// triple (smallest largest radix: fewest registers per butterfly); first radix odd where one exists (conflict-free first-stage
+// writes), else 10, 12, 8, 16, 20, 4, 2 in this order; then the larger middle radix - the choices the measured table makes for
+// 1280 ... 4000 (3200 excepted: 10 x 16 x 20 there, within a few per cent)
+__host__ __device__ constexpr bool gen_auto_three_stages(int n, int (&r)[3])
+{
+    const int S[14] = {25, 20, 16, 15, 13, 12, 11, 10, 8, 7, 5, 4, 3, 2};
+    const int evenpref[7] = {10, 12, 8, 16, 20, 4, 2};
+    long best = -1;
+    for (int ia = 0; ia < 14; ia++)
+        for (int ib = 0; ib < 14; ib++) {
+            const int a = S[ia], b = S[ib];
+            if (n % (a * b) != 0) continue;
+            const int c = n / (a * b);
+            bool ok = false;
+            for (int ic = 0; ic < 14; ic++) ok = ok || S[ic] == c;
+            if (!ok) continue;
+            const int mx = a > b ? (a > c ? a : c) : (b > c ? b : c);
+            int apref = 0; // larger is better
+            if (a % 2 == 1) apref = 100 + a;
+            else
+                for (int e = 0; e < 7; e++)
+                    if (evenpref[e] == a) apref = 50 - e;
+            const long score = (long)(64 - mx) * 1000000 + (long)apref * 1000 + b;
+            if (score > best) { best = score; r[0] = a; r[1] = b; r[2] = c; }
+        }
+    return best >= 0;
+}
+
 // factors and stage tables of an n-point row; false if n has a prime factor above 13 or more than 8 stages
 __host__ __device__ constexpr bool factorize(int n, GenFac& f)
 {
@@ -109,6 +151,16 @@ __host__ __device__ constexpr bool factorize(int n, GenFac& f)
             m /= cand[ci];
         }
     if (m != 1) return false;
+#ifdef FDES_GEN_JIT_N
+    {   // run-time compilation of ONE length (gen_jit.cpp): three stages with composite radices where the single radices need more,
+        // chosen as the hand-measured table above suggests (gen_auto_three_stages)
+        int cr[3] = {0, 0, 0};
+        if (n == FDES_GEN_JIT_N && n > 512 && f.nf > 3 && gen_auto_three_stages(n, cr)) {
+            f.nf = 3;
+            for (int q = 0; q < 8; q++) f.radix[q] = q < 3 ? cr[q] : 0;
+        }
+    }
+#endif
     int Ns = 1;
     for (int q = 0; q < f.nf; q++) {
         f.nbf[q] = n / f.radix[q];
@@ -463,13 +515,14 @@ template <int RX> __host__ __device__ constexpr int rdx_slot(int i)
 template <int RX> __device__ __forceinline__ void rdx_dft(cf (&x)[RX], float s)
 {
     if constexpr (RX == 2 || RX == 3 || RX == 4 || RX == 5) pdft<RX, 1>(x, s);
-    else if constexpr (RX == 7 || RX == 8 || RX == 10) {
+    else if constexpr (RX == 7 || RX == 8 || RX == 10 || RX == 11 || RX == 13) {
         cf t[kRxMax];
 #pragma unroll
         for (int i = 0; i < RX; i++) t[i] = x[i];
         if constexpr (RX == 7) dft7(t, s);
         if constexpr (RX == 8) dft8(t, s);
         if constexpr (RX == 10) dft10(t, s);
+        if constexpr (RX == 11 || RX == 13) dft_prime<RX>(t, s);
 #pragma unroll
         for (int i = 0; i < RX; i++) x[i] = t[i];
     } else {
@@ -703,7 +756,7 @@ __device__ __forceinline__ bool gen_outside(int i1, int i2, float md) { return (
 // (the reference's shipped grids 320, 800, 1000: the generic kernel spends ten times the vector instructions per point
 // of the power-of-two kernels on stage bookkeeping and index arithmetic)
 template <int NC, int EPT, int PRE, int MID, int POST, bool STORE_T>
-__global__ __launch_bounds__(gen_threads(NC), (((EPT <= 8 || (NC != 0 && gen_one_image(NC))) && MID != MID_GTABN) ? 4 : 2)) void k_gpass(PassArgs A, GenFac Frt) // EPT <= 8 (rows up to 1024 points): two workgroups per CU (the species loop of MID_GTABN needs more than 128 registers)
+__device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
 {
     constexpr bool CT = NC != 0;
     constexpr GenFac FC = make_fac(CT ? NC : 320);
@@ -1051,18 +1104,81 @@ __global__ __launch_bounds__(gen_threads(NC), (((EPT <= 8 || (NC != 0 && gen_one
         store_tile(reinterpret_cast<cf*>(A.out2) + ((A.nbatch > 1) ? (size_t)bz * A.bstride_out2 : (size_t)0));
     }
 }
+// waves per SIMD the register allocation is held to: EPT <= 8 (rows up to 1024 points) and the one-image kernels: two workgroups
+// per CU (the species loop of MID_GTABN needs more than 128 registers)
+#define FDES_GPASS_BOUNDS(NC, EPT, MID) __launch_bounds__(fdes::gen_threads(NC), ((((EPT) <= 8 || ((NC) != 0 && fdes::gen_one_image(NC))) && (MID) != fdes::MID_GTABN) ? 4 : 2))
+template <int NC, int EPT, int PRE, int MID, int POST, bool STORE_T>
+__global__ FDES_GPASS_BOUNDS(NC, EPT, MID) void k_gpass(PassArgs A, GenFac Frt)
+{
+    gpass_body<NC, EPT, PRE, MID, POST, STORE_T>(A, Frt);
+}
 
 #undef float2
 #undef make_float2
+
+#ifdef __HIPCC_RTC__
+} // namespace
+} // namespace fdes
+// run-time compilation: the passes of ONE length, exported by name (gen_jit.cpp looks them up as fdes_jit_gpass_<pre>_<mid>_<post>_<t>)
+#define FDES_JIT_KERNEL(P_, M_, Q_, S_)                                                                                          \
+    extern "C" __global__ FDES_GPASS_BOUNDS(FDES_GEN_JIT_N, FDES_GEN_JIT_EPT, M_) void fdes_jit_gpass_##P_##_##M_##_##Q_##_##S_(     \
+        fdes::PassArgs A, fdes::GenFac F)                                                                                        \
+    {                                                                                                                            \
+        fdes::gpass_body<FDES_GEN_JIT_N, FDES_GEN_JIT_EPT, P_, M_, Q_, (S_ != 0)>(A, F);                                         \
+    }
+FDES_JIT_KERNEL(0, 0, 0, 0)
+FDES_JIT_KERNEL(0, 0, 0, 1)
+FDES_JIT_KERNEL(0, 7, 0, 1)
+FDES_JIT_KERNEL(1, 0, 0, 0)
+FDES_JIT_KERNEL(2, 0, 0, 0)
+FDES_JIT_KERNEL(2, 7, 0, 0)
+FDES_JIT_KERNEL(1, 0, 0, 1)
+FDES_JIT_KERNEL(2, 0, 0, 1)
+FDES_JIT_KERNEL(1, 9, 0, 1)
+FDES_JIT_KERNEL(2, 12, 1, 1)
+FDES_JIT_KERNEL(1, 2, 2, 1)
+FDES_JIT_KERNEL(1, 8, 2, 1)
+FDES_JIT_KERNEL(1, 4, 2, 1)
+FDES_JIT_KERNEL(2, 5, 1, 1)
+FDES_JIT_KERNEL(0, 5, 1, 1)
+FDES_JIT_KERNEL(1, 6, 2, 1)
+#else
+
+// launch geometry of a pass over the rows of `a` (shared by the compiled-in and the run-time-compiled kernels)
+struct GLaunch {
+    PassArgs w;
+    dim3 grid;
+    size_t lds_bytes = 0;
+};
+inline hipError_t gen_launch_geometry(const PassArgs& a, const GenFac& f, bool ct, int mid, GLaunch& L)
+{
+    // one or two images of the tile + the twiddle table
+    const bool one = ct && gen_one_image(f.n);
+    const int tw_mode = ct ? gen_tw_mode(f.n, f.rows, one) : (gen_tw_in_lds(f.n) ? 1 : 0);
+    L.lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * (one ? 1 : 2) + (tw_mode == 1 ? (size_t)f.n : (tw_mode == 2 ? (size_t)f.n / 2 : (size_t)0))) + 64;
+    if (L.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (a.nrows % f.rows != 0) return hipErrorInvalidValue;
+    int groups = a.nrows / f.rows;
+    L.w = a;
+    if (a.live_rows_only) {
+        if (a.band <= 0) return hipErrorInvalidValue;
+        const int L_ = a.band_L;
+        const int g_lo = L_ / f.rows + 1, g_hi = (a.nrows - L_) / f.rows;
+        if (g_hi > g_lo) groups = g_lo + (a.nrows / f.rows - g_hi);
+        else L.w.live_rows_only = 0;
+    }
+    const int ny = (mid == MID_ATOMS) ? (a.nspecies > 0 ? a.nspecies : 1) : 1;
+    if (a.nbatch > 16) return hipErrorInvalidValue;
+    const int nz = a.nbatch > 1 ? a.nbatch : 1;
+    L.grid = dim3(groups, ny, nz);
+    L.w.jit = nullptr; // host side only
+    return hipSuccess;
+}
 
 template <int NC, int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaunch(const PassArgs& a, const GenFac& f, hipStream_t st)
 {
     static std::atomic<unsigned long long> attr_set{0};
     auto kern = k_gpass<NC, EPT, PRE, MID, POST, ST>;
-    // two images of the tile + the twiddle table
-    constexpr bool ONE = NC != 0 && gen_one_image(NC);
-    const int tw_mode = NC != 0 ? gen_tw_mode(f.n, f.rows, ONE) : (gen_tw_in_lds(f.n) ? 1 : 0);
-    const size_t lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * (ONE ? 1 : 2) + (tw_mode == 1 ? (size_t)f.n : (tw_mode == 2 ? (size_t)f.n / 2 : (size_t)0))) + 64;
     int dev = 0;
     {
         hipError_t e = hipGetDevice(&dev);
@@ -1073,27 +1189,40 @@ template <int NC, int EPT, int PRE, int MID, int POST, bool ST> hipError_t glaun
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
-    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    if (a.nrows % f.rows != 0) return hipErrorInvalidValue;
-    int groups = a.nrows / f.rows;
-    PassArgs w = a;
-    if (a.live_rows_only) {
-        if (a.band <= 0) return hipErrorInvalidValue;
-        const int L = a.band_L;
-        const int g_lo = L / f.rows + 1, g_hi = (a.nrows - L) / f.rows;
-        if (g_hi > g_lo) groups = g_lo + (a.nrows / f.rows - g_hi);
-        else w.live_rows_only = 0;
+    GLaunch L;
+    {
+        hipError_t e = gen_launch_geometry(a, f, NC != 0, MID, L);
+        if (e != hipSuccess) return e;
     }
-    const int ny = (MID == MID_ATOMS) ? (a.nspecies > 0 ? a.nspecies : 1) : 1;
-    if (a.nbatch > 16) return hipErrorInvalidValue;
-    const int nz = a.nbatch > 1 ? a.nbatch : 1;
+    PassArgs& w = L.w;
     if (a.ev_start && a.ev_stop) {
         w.ev_start = w.ev_stop = nullptr;
-        hipExtLaunchKernelGGL(kern, dim3(groups, ny, nz), dim3(gen_threads(NC)), lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w, f);
+        hipExtLaunchKernelGGL(kern, L.grid, dim3(gen_threads(NC)), L.lds_bytes, st, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, w, f);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(groups, ny, nz), dim3(gen_threads(NC)), lds_bytes, st, w, f);
+    hipLaunchKernelGGL(kern, L.grid, dim3(gen_threads(NC)), L.lds_bytes, st, w, f);
     return hipGetLastError();
+}
+
+// the same pass on the kernels that hipRTC compiled for this length (gen_jit.cpp): k_gpass<n, ...> of the module
+inline hipError_t glaunch_module(const GenJitKernels* k, int pre, int mid, int post, bool st_t, const PassArgs& a, const GenFac& f, hipStream_t st)
+{
+    hipFunction_t fn = reinterpret_cast<hipFunction_t>(gen_jit_function(k, pre, mid, post, st_t));
+    if (!fn) return hipErrorInvalidValue;
+    GLaunch L;
+    {
+        hipError_t e = gen_launch_geometry(a, f, true, mid, L);
+        if (e != hipSuccess) return e;
+    }
+    PassArgs w = L.w;
+    GenFac ff = f;
+    void* params[] = {&w, &ff};
+    if (a.ev_start && a.ev_stop) {
+        w.ev_start = w.ev_stop = nullptr;
+        return hipExtModuleLaunchKernel(fn, L.grid.x * (unsigned)k->threads, L.grid.y, L.grid.z, (unsigned)k->threads, 1, 1, L.lds_bytes, st, params, nullptr,
+                                        (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0);
+    }
+    return hipModuleLaunchKernel(fn, L.grid.x, L.grid.y, L.grid.z, (unsigned)k->threads, 1, 1, (unsigned)L.lds_bytes, st, params, nullptr);
 }
 
 template <int NC, int EPT> hipError_t gdispatch(int pre, int mid, int post, bool st_t, const PassArgs& a, const GenFac& f, hipStream_t st)
@@ -1129,6 +1258,7 @@ bool gen_pass_supported_len(int n)
     return factorize(n, f);
 }
 int gen_pass_rows(int n) { return gen_rows(n); }
+bool gen_pass_compiled_in(int n) { return FDES_GEN_SPECIALISED && gen_specialised(n); }
 
 void gen_pass_twiddles(int n, float* tw)
 {
@@ -1146,6 +1276,11 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
     f.rows = gen_rows(n);
     f.lrows = gen_lrows(f.rows);
     const int ept = (f.rows * n + kGenThreads - 1) / kGenThreads;
+    if (a.jit) { // kernels compiled for this length at plan creation (gen_jit.cpp)
+        const GenJitKernels* k = static_cast<const GenJitKernels*>(a.jit);
+        int dev = -1;
+        if (k->n == n && hipGetDevice(&dev) == hipSuccess && dev == k->device) return glaunch_module(k, pre, mid, post, st_t, a, f, st);
+    }
     if (FDES_GEN_SPECIALISED) { // the grids the reference ships (bin/dataFDES.cnf, bin/test.qsc, Si_001_11k_cnf) and a few round ones
         if (n == 320) return gdispatch<320, 8>(pre, mid, post, st_t, a, f, st);
         if (n == 800) return gdispatch<800, 8>(pre, mid, post, st_t, a, f, st);
@@ -1163,6 +1298,10 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
         if (n == 3200) return gdispatch<3200, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
         if (n == 3600) return gdispatch<3600, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
         if (n == 4000) return gdispatch<4000, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
+#ifdef FDES_GEN_EXTRA_A // experiment: what would a compile-time kernel buy for a length that has none? (-DFDES_GEN_EXTRA_A=1100 -DFDES_GEN_EXTRA_B=2288)
+        if (n == FDES_GEN_EXTRA_A) return gdispatch<FDES_GEN_EXTRA_A, (FDES_GEN_EXTRA_A <= 1024 ? 8 : 16)>(pre, mid, post, st_t, a, f, st);
+        if (n == FDES_GEN_EXTRA_B) return gdispatch<FDES_GEN_EXTRA_B, (FDES_GEN_EXTRA_B <= 1024 ? 8 : 16)>(pre, mid, post, st_t, a, f, st);
+#endif
     }
     if (ept <= 8) return gdispatch<0, 8>(pre, mid, post, st_t, a, f, st);
     if (ept <= 16) return gdispatch<0, 16>(pre, mid, post, st_t, a, f, st);
@@ -1170,3 +1309,4 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
 }
 
 } // namespace fdes
+#endif // __HIPCC_RTC__

@@ -7,8 +7,10 @@
 // and never runs a stand-alone point-wise kernel ("Fused slice loop").
 #ifndef FDES_FFT_LDS_H_
 #define FDES_FFT_LDS_H_
+#ifndef __HIPCC_RTC__ // (fft_gen.hip is also compiled by hipRTC at run time: the runtime's own declarations are built in there)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#endif
 
 namespace fdes {
 
@@ -93,8 +95,11 @@ struct PassArgs {
     // marker packets before and after it
     void* ev_start = nullptr;
     void* ev_stop = nullptr;
+    // host side only: the kernels hipRTC compiled for this row length at plan creation (GenJitKernels, gen_jit.h), or nullptr
+    const void* jit = nullptr;
 };
 
+#ifndef __HIPCC_RTC__
 // Row lengths the register-resident kernels are instantiated for (powers of two, 256 ... 4096); lds_pass() also takes
 // the lengths of gen_pass_supported_len().
 bool lds_fft_supported_len(int n);
@@ -117,6 +122,7 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool store_transposed, co
 
 // Launch one pass over all rows. n = row length, kinds select the template instantiation.
 hipError_t lds_pass(int n, int pre, int mid, int post, bool store_transposed, const PassArgs& a, hipStream_t st);
+#endif // __HIPCC_RTC__
 
 } // namespace fdes
 #endif

@@ -1,0 +1,31 @@
+// gen_jit.h — run-time compilation of the mixed-radix row passes for one grid length (gen_jit.cpp).
+#ifndef FDES_GEN_JIT_H_
+#define FDES_GEN_JIT_H_
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+namespace fdes {
+
+// the compile-time form of fft_gen.hip's passes for ONE row length, compiled by hipRTC and loaded on one device
+struct GenJitKernels {
+    static constexpr int kCount = 16; // the pass kinds of gen_pass()
+    int n = 0, device = 0, threads = 512;
+    void* module = nullptr;           // hipModule_t
+    void* fn[kCount] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+// FDES_JIT != "0"
+bool gen_jit_default_on();
+// The kernels of the n-point passes on the CURRENT device: from this process, from the directory cache, or compiled now (seconds).
+// nullptr: n has compiled-in kernels or is no mixed-radix length (note stays empty), or hipRTC is missing / the compilation
+// failed (note says why; the run-time-length kernels serve the length).  Call at plan creation, never inside a stream capture.
+const GenJitKernels* gen_jit_prepare(int n, std::string* note);
+// hipFunction_t of one pass kind, nullptr if there is none
+void* gen_jit_function(const GenJitKernels* k, int pre, int mid, int post, bool store_transposed);
+
+// fft_gen.hip: lengths whose compile-time kernels are part of the library
+bool gen_pass_compiled_in(int n);
+
+} // namespace fdes
+#endif

@@ -1,8 +1,10 @@
 // geometry.h — host-callable launchers of geometry.hip.
 #ifndef FDES_GEOMETRY_H_
 #define FDES_GEOMETRY_H_
+#ifndef __HIPCC_RTC__ // (run-time compilation of fft_gen.hip only needs AtomRec)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace fdes {
 
@@ -18,6 +20,7 @@ struct AtomRec {
     int pad;
 };
 
+#ifndef __HIPCC_RTC__
 struct AtomBins { // device buffers of the per-configuration binning, key = (slice * nZ + species) * m2 + row
     uint32_t *keys = nullptr, *keys_sorted = nullptr, *vals = nullptr, *order = nullptr;
     int* seg = nullptr;      // [m3*nZ + 2]  first sorted position of every (slice, species)
@@ -52,6 +55,7 @@ inline bool geom_deposit_tile_fits(int m1) { return m1 > 0 && sizeof(float2) * (
 hipError_t geom_deposit_tile(float2* V, const AtomBins& b, int key0, int key1, bool with_impot, float imPot, const BinGeom& g, hipStream_t st);
 hipError_t geom_deposit_pair(float2* V, const float* xyz, const float* occ, const AtomBins& b, int key0, int key1, const BinGeom& g,
                              int blocks, hipStream_t st);
+#endif // __HIPCC_RTC__
 
 } // namespace fdes
 #endif

@@ -7,6 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # rocFFT compiles kernels for sizes outside its prebuilt set at plan time (tens of seconds each on a fresh
 # box); keep its cache in-tree (git-ignored, travels with the gpurun snapshot like the built .so files).
 os.environ.setdefault("ROCFFT_RTC_CACHE_PATH", os.path.join(ROOT, "fdes_amd", "csrc", "build", "rocfft_rtc_cache.db"))
+# Grid lengths without compiled-in mixed-radix kernels get theirs compiled by hipRTC at plan creation (gen_jit.cpp: seconds per
+# length).  The suite keeps that OFF by default, so that the run-time-length kernels - the fallback of every such length - stay
+# covered and twenty lengths do not cost two minutes of compilation; the tests of the run-time compilation ask for it (jit = 1).
+os.environ.setdefault("FDES_JIT", "0")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

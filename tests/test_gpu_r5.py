@@ -84,3 +84,82 @@ def test_slice_loop_capture_beside_plan_creation_in_another_thread(tmp_path, loc
     r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
     print(r.stdout[-300:], r.stderr[-1500:])
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# run-time compilation of the mixed-radix row passes for a grid length without compiled-in kernels (gen_jit.cpp)
+# ------------------------------------------------------------------------------------------------------------------
+
+def test_run_time_compiled_kernels_against_oracle(oracle, tmp_path, monkeypatch):
+    """cufftPlan2d serves any size alike (src/paramStructure.cu:676-679).  A grid length without compiled-in kernels (1100 =
+    2 nx of a .qsc with nx = 550) gets the compile-time form of its row passes from hipRTC at plan creation: both axes report
+    such kernels, the slice loop (one and two species, with and without the empty-slice short cut) meets the float64 oracle,
+    the code object lands in the directory cache, and the run-time-length kernels (jit = 0) give the same physics."""
+    monkeypatch.setenv("FDES_JIT_CACHE", str(tmp_path / "jit"))
+    for m, nz in ((1100, 1), (572, 2)):
+        hp, at = S.case_tiny(m=m, m3=5, nz=nz, nat=300, tilt=True, seed=51 + nz)
+        fdes_amd.consistent(hp)
+        q, _ = oracle.sub_sliced(hp)
+        ref = oracle.wave(q, at, 0, 0, prec="f64")
+        r32 = oracle.wave(q, at, 0, 0, prec="f32")
+        waves = {}
+        for jit in (1, 0):
+            for skip in (0, 1):
+                eng = fdes_amd.Engine(0, skip_empty=skip, jit=jit)
+                pl = eng.plan(hp, at)
+                assert pl.fft_backend() == 2 and pl.jit_kernels() == (2 if jit else 0)
+                psi = pl.tap_wave(0, 0)
+                check(psi, ref, r32, 1e-5, f"run-time-compiled kernels {m}^2 nz={nz} jit={jit} skip_empty={skip}")
+                if skip == 0:
+                    waves[jit] = psi
+                    if jit:
+                        xyz = oracle.config_coords(q, at, 0, -1)
+                        V = pl.tap_potential(0, 0, 2)
+                        check(V, oracle.phase_grating(q, at, xyz, 2, "f64"), None, 1e-5, f"run-time-compiled kernels, potential s=2 {m}^2 nz={nz}")
+                pl.close()
+                eng.close()
+        assert relerr(waves[1], waves[0]) < 2e-6
+    cached = sorted(p.name for p in (tmp_path / "jit").iterdir())
+    assert len(cached) == 2 and cached[0].startswith("gpass_1100_") and cached[1].startswith("gpass_572_"), cached
+    assert all((tmp_path / "jit" / n).read_bytes()[:4] == b"\x7fELF" for n in cached)
+
+
+def test_run_time_compiled_kernels_whole_driver_and_mixed_axes(oracle, tmp_path, monkeypatch):
+    """Whole driver (lanes, graph replay, gangs, detector chain) on run-time-compiled kernels: a frozen-phonon image at 660^2
+    (660 = 4 * 3 * 5 * 11) against the float32 oracle; a rectangular grid with ONE such axis (2288 x 1024: a two-row-tile length
+    beside a power of two) reports one compiled axis and meets the float64 oracle; a length with compiled-in kernels (1000) and a
+    power of two report none; the FFT alone at 2288 x 1716 (two compiled lengths) against numpy."""
+    monkeypatch.setenv("FDES_JIT_CACHE", str(tmp_path / "jit"))
+    hp, at = S.case_tiny(m=660, m3=6, nz=2, frPh=3, nat=200, tilt=True)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0, jit=1)
+    pl = eng.plan(hp, at)
+    assert pl.jit_kernels() == 2
+    pl.close()
+    img = eng.build_measurements(hp, at)["image"]
+    eng.close()
+    e = relerr(img, oracle.build_measurements(hp, at, prec="f32")["image"])
+    print(f"[parity] run-time-compiled kernels, driver 660^2 frPh=3: E = {e:.3e}")
+    assert e <= 1e-5
+    hp, at = S.case_tiny(m=2288, m2=1024, m3=3, nz=1, nat=200, tilt=True, seed=5)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0, jit=1)
+    pl = eng.plan(hp, at)
+    assert pl.fft_backend() == 2 and pl.jit_kernels() == 1
+    pl.close()
+    out = eng.build_measurements(hp, at)["image"]
+    check(out, oracle.build_measurements(hp, at, prec="f64")["image"], None, 1e-5, "run-time-compiled kernels on one axis, 2288 x 1024")
+    for m in (1000, 2048):
+        hp2, at2 = S.case_tiny(m=m, m3=2, nz=1, nat=20)
+        fdes_amd.consistent(hp2)
+        pl = eng.plan(hp2, at2)
+        assert pl.jit_kernels() == 0
+        pl.close()
+    rng = np.random.default_rng(7)
+    f = (rng.standard_normal((1716, 2288)) + 1j * rng.standard_normal((1716, 2288))).astype(np.complex64)
+    for inv in (False, True):
+        o, used = eng.fft2(f, inv, backend=2)
+        assert used == 2
+        ref = np.fft.ifft2(f.astype(np.complex128)) * f.size if inv else np.fft.fft2(f.astype(np.complex128))
+        assert relerr(o, ref) < 6e-7
+    eng.close()

@@ -53,15 +53,16 @@ def test_export_list_without_test_hooks(tmp_path):
 
 
 def test_library_builds_from_clean(tmp_path):
-    """Every object of the library from scratch into a scratch directory (the in-tree build reuses objects): all 16
-    translation units for gfx950 and the link with the export list - as a `make TEST_HOOKS=0` build, the one a maintainer
+    """Every object of the library from scratch into a scratch directory (the in-tree build reuses objects): all 17
+    translation units for gfx950 (gen_jit.cpp with the text of fft_gen.hip that the Makefile writes beside the objects) and the
+    link with the export list - as a `make TEST_HOOKS=0` build, the one a maintainer
     ships: it exports the product entry points only, and fdes_amd/abi.py loads it (the hook prototypes are optional there: a
     call of one fails loudly)."""
     csrc = os.path.join(ROOT, "fdes_amd", "csrc")
     lib = tmp_path / "libFDES_SHARED_LIB.so"
     r = subprocess.run(["make", "-s", "-j8", "-C", csrc, f"B={tmp_path}/build", f"LIB={lib}", "TEST_HOOKS=0", str(lib)], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert len(os.listdir(tmp_path / "build")) == 17   # 16 objects + exports.map
+    assert len(os.listdir(tmp_path / "build")) == 19   # 17 objects + exports.map + gen_jit_src.inc
     out = subprocess.run(["nm", "-D", "--defined-only", str(lib)], capture_output=True, text=True, check=True).stdout
     prod = set(open(os.path.join(csrc, "exports_product.txt")).read().split())
     assert {l.split()[-1] for l in out.splitlines()} == prod
@@ -71,6 +72,39 @@ def test_library_builds_from_clean(tmp_path):
             "try:\n    lib.fdes_plan_probe_ms(None, None, None)\nexcept RuntimeError as e:\n    print('hook refused:', e)\n" % (ROOT, str(lib)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "hook refused" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n,ept", [(1100, 16), (720, 8), (3840, 16)])
+def test_mixed_radix_source_compiles_under_hiprtc(n, ept):
+    """gen_jit.cpp hands hipRTC the text of fft_gen.hip (+ fft_lds.h, geometry.h, fft_dev.inc) with -DFDES_GEN_JIT_N=<length> at
+    plan creation: the same text with the same options must compile here (no GPU needed) and export the sixteen pass kernels
+    by name - the guards around the host side of these files are part of the product."""
+    csrc = os.path.join(ROOT, "fdes_amd", "csrc")
+    try:
+        rtc = C.CDLL("libhiprtc.so")
+    except OSError:
+        rtc = C.CDLL("/opt/rocm/lib/libhiprtc.so")
+    src = open(os.path.join(csrc, "fft_gen.hip"), "rb").read()
+    names = [b"fft_lds.h", b"geometry.h", b"fft_dev.inc"]
+    hdrs = [open(os.path.join(csrc, f.decode()), "rb").read() for f in names]
+    prog = C.c_void_p()
+    A = C.c_char_p * 3
+    assert rtc.hiprtcCreateProgram(C.byref(prog), src, b"fft_gen.hip", 3, A(*hdrs), A(*names)) == 0
+    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-munsafe-fp-atomics", b"-DFDES_TEST_HOOKS=0", b"-DFDES_GEN_JIT_N=%d" % n, b"-DFDES_GEN_JIT_EPT=%d" % ept]
+    rc = rtc.hiprtcCompileProgram(prog, len(opts), (C.c_char_p * len(opts))(*opts))
+    ls = C.c_size_t()
+    rtc.hiprtcGetProgramLogSize(prog, C.byref(ls))
+    log = C.create_string_buffer(max(ls.value, 1))
+    rtc.hiprtcGetProgramLog(prog, log)
+    assert rc == 0, log.value.decode(errors="replace")[-3000:]
+    cs = C.c_size_t()
+    assert rtc.hiprtcGetCodeSize(prog, C.byref(cs)) == 0 and cs.value > 10000
+    code = C.create_string_buffer(cs.value)
+    assert rtc.hiprtcGetCode(prog, code) == 0
+    raw = code.raw
+    for kind in ("0_0_0_0", "1_9_0_1", "2_12_1_1", "1_2_2_1", "1_8_2_1", "1_4_2_1", "2_5_1_1", "0_5_1_1", "1_6_2_1"):
+        assert b"fdes_jit_gpass_" + kind.encode() in raw, kind
+    rtc.hiprtcDestroyProgram(C.byref(prog))
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
