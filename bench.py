@@ -507,38 +507,48 @@ def run_extras(device):
                  "passes": table}
     pl.close()
     eng.close()
-    # A grid length that is not a power of two (round 4): m = 2 nx of a .qsc with nx = 1500 (src/rwQsc.cu:943-948) = 3000, on the
-    # fused mixed-radix passes (until round 3: rocFFT + point-wise kernels); C3 specimen, 32 slices, 2 untimed + 6 timed
-    # configurations, every slice the full sequence
-    hp, at = specimens.case_c3(k=30, n=1500, dn=750, m3=32, frPh=32)
-    fdes_amd.consistent(hp)
-    eng = fdes_amd.Engine(device, skip_empty=0)
-    pl = eng.plan(hp, at)
-    pl.begin_measurement(0)
-    for j in range(2):
-        pl.run_config(0, 100 + j, 0.0)
-    pl.sync()
-    torch.cuda.synchronize()
-    n = 6
-    rates = []
-    for rep in range(5):
+    # Grid lengths that are not powers of two: m = 2 nx of a .qsc (src/rwQsc.cu:943-948).  nx = 1500 -> 3000 points (round 4: on the
+    # fused mixed-radix passes with compiled-in kernels; until round 3: rocFFT + point-wise kernels); nx = 1144 -> 2288 = 16 x 11 x 13
+    # points (round 5: no compiled-in kernels - the row passes are compiled for the length by hipRTC when the plan is created,
+    # gen_jit.cpp; `plan_creation_s` holds that compilation, or the read from the directory cache).  C3 specimen, 32 slices,
+    # 2 untimed + 6 timed configurations, every slice the full sequence
+    def grid_extra(nx):
+        hp, at = specimens.case_c3(k=30, n=nx, dn=nx // 2, m3=32, frPh=32)
+        fdes_amd.consistent(hp)
+        eng = fdes_amd.Engine(device, skip_empty=0)
         t0 = time.perf_counter()
-        for j in range(n):
-            pl.run_config(0, j, 1.0 / 160)
+        pl = eng.plan(hp, at)
+        t_plan = time.perf_counter() - t0
+        pl.begin_measurement(0)
+        for j in range(2):
+            pl.run_config(0, 100 + j, 0.0)
         pl.sync()
         torch.cuda.synchronize()
-        rates.append(n * pl.m3 / (time.perf_counter() - t0))
-    pl.end_measurement(0)
-    img = pl.get_images()
-    rate = float(np.median(rates))
-    out["qsc_sized_grid"] = {"workload": f"C3 specimen ({at.n} atoms) on a 3000x3000 wave (m = 2 nx, nx = 1500), {pl.m3} slices, {n} configurations per repetition, 5 repetitions",
-                             "value": round(rate, 1), "min": round(min(rates), 1), "median": round(rate, 1), "max": round(max(rates), 1),
-                             "unit": "slice-propagations/s", "lanes": pl.lanes(),
-                             "slice_loop": "fused LDS passes" if pl.fft_backend() == 2 else "rocFFT + point-wise kernels",
-                             "whole_step_frac": round(ENGINE_BYTES_PER_PX_SLICE * 9.0e6 * rate / 8e12, 4),
-                             "finite": bool(np.isfinite(img).all())}
-    pl.close()
-    eng.close()
+        n = 6
+        rates = []
+        for rep in range(5):
+            t0 = time.perf_counter()
+            for j in range(n):
+                pl.run_config(0, j, 1.0 / 160)
+            pl.sync()
+            torch.cuda.synchronize()
+            rates.append(n * pl.m3 / (time.perf_counter() - t0))
+        pl.end_measurement(0)
+        img = pl.get_images()
+        rate = float(np.median(rates))
+        m = 2 * nx
+        r = {"workload": f"C3 specimen ({at.n} atoms) on a {m}x{m} wave (m = 2 nx, nx = {nx}), {pl.m3} slices, {n} configurations per repetition, 5 repetitions",
+             "value": round(rate, 1), "min": round(min(rates), 1), "median": round(rate, 1), "max": round(max(rates), 1),
+             "unit": "slice-propagations/s", "lanes": pl.lanes(),
+             "slice_loop": "fused LDS passes" if pl.fft_backend() == 2 else "rocFFT + point-wise kernels",
+             "run_time_compiled_axes": pl.jit_kernels(), "plan_creation_s": round(t_plan, 2),
+             "whole_step_frac": round(ENGINE_BYTES_PER_PX_SLICE * float(m) * float(m) * rate / 8e12, 4),
+             "finite": bool(np.isfinite(img).all())}
+        pl.close()
+        eng.close()
+        return r
+    out["qsc_sized_grid"] = grid_extra(1500)
+    out["run_time_compiled_grid"] = grid_extra(1144)
     # BASELINE config 4 at full size: SrTiO3 beam-tilt series, 64 tilts x 8 frozen-phonon configurations, 1024^2 wave, 40
     # slices, every slice the full sequence; engine defaults (lanes of gangs); one untimed job, one timed job
     hp, at = specimens.case_c4()
