@@ -96,7 +96,7 @@ def main():
 
     m = args.size
     k_au = 30 if m >= 2048 else max(2, int(30 * m / 2048))
-    hp, atoms = specimens.case_c3(k=k_au, n=m // 2, dn=m // 4, m3=args.slices, frPh=32)
+    hp, atoms = specimens.case_c3(k=k_au, n=m - 2 * (m // 4), dn=m // 4, m3=args.slices, frPh=32)   # (n + 2 dn = m also where four does not divide m)
     fdes_amd.consistent(hp)
     probe_lanes = {"ms": 0.0, "n": 0, "passes": None}
 

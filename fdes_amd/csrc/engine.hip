@@ -432,8 +432,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
     }
     if (pl->fused) {
         const int m1 = pl->p.m1, m2 = pl->p.m2;
-        const bool ok256 = (m2 % lds_fft_rows_per_block(m1, 256) == 0) && (m1 % lds_fft_rows_per_block(m2, 256) == 0) &&
-                           lds_fft_rows_per_block(m1, 256) >= 4 && lds_fft_rows_per_block(m2, 256) >= 4; // >= 32-byte transposed segments
+        const bool ok256 = lds_fft_rows_per_block(m1, 256, m2) >= 4 && lds_fft_rows_per_block(m2, 256, m1) >= 4; // the rows per workgroup divide the other dimension; >= 32-byte transposed segments
         // 256-thread workgroups (two per CU) measured faster or equal for every pass up to 2048-point rows, with one
         // or two lanes; 4096-point rows keep 512 threads (256 would cut the transposed-store segments to 16 bytes)
         // up to 1024^2 a pass is as long as its slowest workgroup: one row per thread, four rows per workgroup
@@ -448,7 +447,7 @@ int fdes_plan_create(fdes_ctx* c, const fdes_params* p_in, const fdes_atoms* a, 
         else if ((c->pass_threads == 1 || c->pass_threads == 513 || (c->pass_threads == 0 && small)) && m1 <= 2048 && m2 <= 2048) pl->wg = 1;
         else pl->wg = ok256 ? 256 : 512;
         // (mixed grids, e.g. 1000 x 512: the rows per workgroup of one axis must divide the other axis)
-        if (m2 % lds_fft_rows_per_block(m1, pl->wg) != 0 || m1 % lds_fft_rows_per_block(m2, pl->wg) != 0) pl->wg = pl->fft->wg;
+        if (lds_fft_rows_per_block(m1, pl->wg, m2) <= 0 || lds_fft_rows_per_block(m2, pl->wg, m1) <= 0) pl->wg = pl->fft->wg;
         // Slice-loop working set: the transient grids share buffers (A -> [P2] -> B; B -> [P3] -> C, C2; C | C2 -> [P4] -> E;
         // E, PSIH -> [P5] -> F; F -> [P6] -> PSIH: A, C and F are never live together, nor are B and E), and the
         // lanes share the read-only tables PT / GT: 4 grids per lane + the tables instead of 7.5 per lane, so that two

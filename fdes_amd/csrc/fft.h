@@ -28,6 +28,7 @@ struct Fft2D {
     int wg = 512; // workgroup geometry of the LDS passes (PassArgs::wg)
     // kernels compiled at run time for a mixed-radix row length without compiled-in ones (gen_jit.h; PassArgs::jit), per axis
     const void *jit_x = nullptr, *jit_y = nullptr;
+    int rows_x = 0, rows_y = 0; // mixed-radix axes: rows per tile (PassArgs::tile_rows; gen_pass_tile_rows), 0 for the other kernels
     std::string jit_note; // why a length that could have them runs the run-time-length kernels instead
 
     static bool lds_supported(int m1, int m2);

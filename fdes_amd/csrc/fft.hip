@@ -19,7 +19,7 @@ int Fft2D::pick_wg(int m1, int m2)
     if (!(lds_fft_supported_len(m1) || gen_pass_supported_len(m1)) || !(lds_fft_supported_len(m2) || gen_pass_supported_len(m2))) return 0;
     for (int wg : {512, 256, 1}) {
         if (wg == 1 && (m1 > 2048 || m2 > 2048)) continue;
-        if (m2 % lds_fft_rows_per_block(m1, wg) == 0 && m1 % lds_fft_rows_per_block(m2, wg) == 0) return wg;
+        if (lds_fft_rows_per_block(m1, wg, m2) > 0 && lds_fft_rows_per_block(m2, wg, m1) > 0) return wg;
     }
     return 0;
 }
@@ -56,9 +56,12 @@ int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err, b
         if (upload_twiddles(m1, &tw0x, &tw1x, st, err)) return -1;
         if (upload_twiddles(m2, &tw0y, &tw1y, st, err)) return -1;
         if (hipMalloc((void**)&scratch, sizeof(float2) * (size_t)m1 * m2) != hipSuccess) { if (err) *err = "scratch allocation failed"; return -1; }
-        if (jit) { // a mixed-radix length without compiled-in kernels: compile them now (or take them from the cache); failure is not an error
-            jit_x = gen_jit_prepare(m1, &jit_note);
-            jit_y = (m2 == m1) ? jit_x : gen_jit_prepare(m2, &jit_note);
+        // mixed-radix axes: tiles smaller than the length's own where those do not divide the other dimension
+        rows_x = gen_pass_supported_len(m1) ? gen_pass_tile_rows(m1, m2) : 0;
+        rows_y = gen_pass_supported_len(m2) ? gen_pass_tile_rows(m2, m1) : 0;
+        if (jit) { // a mixed-radix length without compiled-in kernels (for these tile rows): compile them now (or take them from the cache); failure is not an error
+            jit_x = gen_jit_prepare(m1, rows_x, &jit_note);
+            jit_y = (m2 == m1) ? jit_x : gen_jit_prepare(m2, rows_y, &jit_note);
             if (!jit_note.empty() && std::getenv("FDES_JIT_VERBOSE")) std::fprintf(stderr, "  FDES: run-time-length kernels (%s)\n", jit_note.c_str());
         }
         return 0;
@@ -89,11 +92,11 @@ hipError_t Fft2D::exec(float2* data, bool inverse, hipStream_t st)
         // pass 1: rows along x (length m1, m2 rows) -> scratch[kx][y]; pass 2: rows along y -> data[ky][kx]
         const int xf = inverse ? XF_INV : XF_FWD;
         PassArgs a;
-        a.in0 = data; a.out = scratch; a.tw0 = tw0x; a.tw1 = tw1x; a.nrows = m2; a.wg = wg; a.jit = jit_x;
+        a.in0 = data; a.out = scratch; a.tw0 = tw0x; a.tw1 = tw1x; a.nrows = m2; a.wg = wg; a.jit = jit_x; a.tile_rows = rows_x;
         hipError_t e = lds_pass(m1, xf, MID_NONE, XF_NONE, true, a, st);
         if (e != hipSuccess) return e;
         PassArgs b;
-        b.in0 = scratch; b.out = data; b.tw0 = tw0y; b.tw1 = tw1y; b.nrows = m1; b.wg = wg; b.jit = jit_y;
+        b.in0 = scratch; b.out = data; b.tw0 = tw0y; b.tw1 = tw1y; b.nrows = m1; b.wg = wg; b.jit = jit_y; b.tile_rows = rows_y;
         return lds_pass(m2, xf, MID_NONE, XF_NONE, true, b, st);
     }
     void* in[1] = {data};

@@ -189,7 +189,13 @@ __host__ __device__ constexpr bool gen_specialised(int n)
     return n == 320 || n == 800 || n == 1000 || n == 400 || n == 500 || n == 640 || n == 1280 || n == 1600 || n == 2000 || n == 2560 || n == 3000 ||
            n == 3072 || n == 3200 || n == 3600 || n == 4000;
 }
-__host__ __device__ constexpr int gen_rows(int n) { return n > 2048 ? (((FDES_GEN_ROWS4 || FDES_GEN_T1024) && gen_specialised(n)) ? 4 : 2) : (n > 512 ? 4 : 8); }
+__host__ __device__ constexpr int gen_rows(int n)
+{
+#ifdef FDES_GEN_JIT_ROWS // run-time compilation for a grid whose OTHER dimension the length's own tile rows do not divide (gen_pass_tile_rows)
+    if (n == FDES_GEN_JIT_N) return FDES_GEN_JIT_ROWS;
+#endif
+    return n > 2048 ? (((FDES_GEN_ROWS4 || FDES_GEN_T1024) && gen_specialised(n)) ? 4 : 2) : (n > 512 ? 4 : 8);
+}
 constexpr int kGenThreads = 512; // threads of a workgroup (gen_threads below: 1024 for the four-row tiles of FDES_GEN_T1024)
 __host__ __device__ constexpr bool gen_t1024(int n) { return FDES_GEN_T1024 && n > 2048 && gen_specialised(n); }
 __host__ __device__ constexpr int gen_threads(int n) { return gen_t1024(n) ? 1024 : kGenThreads; }
@@ -1258,6 +1264,15 @@ bool gen_pass_supported_len(int n)
     return factorize(n, f);
 }
 int gen_pass_rows(int n) { return gen_rows(n); }
+// Rows per tile for n-point rows of a grid with `nrows` of them: the length's own number (8 up to 512 points, 4 up to 2048, 2
+// beyond) or, where that does not divide nrows, the next smaller power of two that does - 500^2 runs four-row tiles, 750^2 (m = 2 nx
+// of a .qsc with an odd nx) two-row tiles instead of leaving the fused loop; 0: nrows is odd
+int gen_pass_tile_rows(int n, int nrows)
+{
+    for (int r = gen_rows(n); r >= 2; r >>= 1)
+        if (nrows % r == 0) return r;
+    return 0;
+}
 bool gen_pass_compiled_in(int n) { return FDES_GEN_SPECIALISED && gen_specialised(n); }
 
 void gen_pass_twiddles(int n, float* tw)
@@ -1273,15 +1288,15 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
 {
     GenFac f;
     if (!gen_pass_supported_len(n) || !factorize(n, f)) return hipErrorInvalidValue;
-    f.rows = gen_rows(n);
+    f.rows = (a.tile_rows == 2 || a.tile_rows == 4 || a.tile_rows == 8) && a.tile_rows <= gen_rows(n) ? a.tile_rows : gen_rows(n);
     f.lrows = gen_lrows(f.rows);
     const int ept = (f.rows * n + kGenThreads - 1) / kGenThreads;
-    if (a.jit) { // kernels compiled for this length at plan creation (gen_jit.cpp)
+    if (a.jit) { // kernels compiled for this length (and these tile rows) at plan creation (gen_jit.cpp)
         const GenJitKernels* k = static_cast<const GenJitKernels*>(a.jit);
         int dev = -1;
-        if (k->n == n && hipGetDevice(&dev) == hipSuccess && dev == k->device) return glaunch_module(k, pre, mid, post, st_t, a, f, st);
+        if (k->n == n && k->rows == f.rows && hipGetDevice(&dev) == hipSuccess && dev == k->device) return glaunch_module(k, pre, mid, post, st_t, a, f, st);
     }
-    if (FDES_GEN_SPECIALISED) { // the grids the reference ships (bin/dataFDES.cnf, bin/test.qsc, Si_001_11k_cnf) and a few round ones
+    if (FDES_GEN_SPECIALISED && f.rows == gen_rows(n)) { // (the compiled-in kernels have the length's own tile rows) // the grids the reference ships (bin/dataFDES.cnf, bin/test.qsc, Si_001_11k_cnf) and a few round ones
         if (n == 320) return gdispatch<320, 8>(pre, mid, post, st_t, a, f, st);
         if (n == 800) return gdispatch<800, 8>(pre, mid, post, st_t, a, f, st);
         if (n == 1000) return gdispatch<1000, 8>(pre, mid, post, st_t, a, f, st);

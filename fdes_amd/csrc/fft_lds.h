@@ -97,6 +97,8 @@ struct PassArgs {
     void* ev_stop = nullptr;
     // host side only: the kernels hipRTC compiled for this row length at plan creation (GenJitKernels, gen_jit.h), or nullptr
     const void* jit = nullptr;
+    // host side only, mixed-radix passes: rows per tile where the length's own number does not divide nrows (gen_pass_tile_rows); 0: default
+    int tile_rows = 0;
 };
 
 #ifndef __HIPCC_RTC__
@@ -105,6 +107,8 @@ struct PassArgs {
 bool lds_fft_supported_len(int n);
 // rows per workgroup for row length n and wg threads per workgroup (512: one workgroup per CU; 256: two)
 int lds_fft_rows_per_block(int n, int wg);
+// the same for a grid with `nrows` rows of that length: a mixed-radix length may fall back to smaller tiles (gen_pass_tile_rows); 0: none fits
+int lds_fft_rows_per_block(int n, int wg, int nrows);
 // fills host arrays (float2 as 2 floats) with the twiddle tables of length n: tw0[16*T], tw1[T]
 void lds_fft_twiddles(int n, float* tw0, float* tw1);
 
@@ -117,6 +121,7 @@ hipError_t wave_pass(int n, int pre, int mid, int post, bool store_transposed, c
 // their twiddle table is the n roots of unity W_n^k (float2 as 2 floats)
 bool gen_pass_supported_len(int n);
 int gen_pass_rows(int n);
+int gen_pass_tile_rows(int n, int nrows);
 void gen_pass_twiddles(int n, float* tw);
 hipError_t gen_pass(int n, int pre, int mid, int post, bool store_transposed, const PassArgs& a, hipStream_t st);
 

@@ -805,6 +805,13 @@ int lds_fft_rows_per_block(int n, int wg)
     return wg == 1 ? 4 : (wg == 256 ? 256 * 2 : 512 * 2) * 16 / n;
 }
 
+int lds_fft_rows_per_block(int n, int wg, int nrows)
+{
+    if (gen_pass_supported_len(n)) return gen_pass_tile_rows(n, nrows);
+    const int r = lds_fft_rows_per_block(n, wg);
+    return (r > 0 && nrows % r == 0) ? r : 0;
+}
+
 void lds_fft_twiddles(int n, float* tw0, float* tw1)
 {
     const int T = n / 16;

@@ -15,11 +15,11 @@ int fft_gang(fdes_plan* pl, float2* data, int n, size_t stride, bool inverse)
     }
     const int xf = inverse ? XF_INV : XF_FWD;
     PassArgs a;
-    a.in0 = data; a.out = pl->gscr; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.jit = pl->fft->jit_x; a.nrows = pl->p.m2; a.wg = pl->fft->wg;
+    a.in0 = data; a.out = pl->gscr; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.jit = pl->fft->jit_x; a.tile_rows = pl->fft->rows_x; a.nrows = pl->p.m2; a.wg = pl->fft->wg;
     a.nbatch = n; a.bstride_in0 = stride; a.bstride_out = pl->m12;
     HIPCHK(c, lds_pass(pl->p.m1, xf, MID_NONE, XF_NONE, true, a, c->stream));
     PassArgs b;
-    b.in0 = pl->gscr; b.out = data; b.tw0 = pl->fft->tw0y; b.tw1 = pl->fft->tw1y; b.jit = pl->fft->jit_y; b.nrows = pl->p.m1; b.wg = pl->fft->wg;
+    b.in0 = pl->gscr; b.out = data; b.tw0 = pl->fft->tw0y; b.tw1 = pl->fft->tw1y; b.jit = pl->fft->jit_y; b.tile_rows = pl->fft->rows_y; b.nrows = pl->p.m1; b.wg = pl->fft->wg;
     b.nbatch = n; b.bstride_in0 = pl->m12; b.bstride_out = stride;
     HIPCHK(c, lds_pass(pl->p.m2, xf, MID_NONE, XF_NONE, true, b, c->stream));
     return FDES_OK;

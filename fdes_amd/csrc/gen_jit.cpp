@@ -102,29 +102,31 @@ void make_dirs(const std::string& d)
 }
 
 std::mutex g_mu;
-std::map<int, std::vector<char>> g_code;                        // length -> code object (compiled or read from the cache once per process)
-std::map<int, std::string> g_failed;                            // length -> why it has no code object (not tried again)
-std::map<std::pair<int, int>, GenJitKernels*> g_mod;            // (length, device) -> loaded module
+std::map<std::pair<int, int>, std::vector<char>> g_code;        // (length, tile rows) -> code object (compiled or read from the cache once per process)
+std::map<std::pair<int, int>, std::string> g_failed;            // (length, tile rows) -> why it has no code object (not tried again)
+std::map<std::pair<std::pair<int, int>, int>, GenJitKernels*> g_mod; // ((length, tile rows), device) -> loaded module
 
-int ept_of(int n) { const int rows = gen_pass_rows(n); return (rows * n + 511) / 512 <= 8 ? 8 : 16; }
+int ept_of(int n, int rows) { return (rows * n + 511) / 512 <= 8 ? 8 : 16; }
 
 // code object of the n-point passes: from this process, from the directory cache, or compiled now
-const std::vector<char>* code_for(int n, std::string* note)
+const std::vector<char>* code_for(int n, int rows, std::string* note)
 {
-    auto it = g_code.find(n);
+    const std::pair<int, int> key{n, rows};
+    auto it = g_code.find(key);
     if (it != g_code.end()) return &it->second;
-    auto fl = g_failed.find(n);
+    auto fl = g_failed.find(key);
     if (fl != g_failed.end()) { if (note) *note = fl->second; return nullptr; }
     Rtc& R = rtc();
     auto fail = [&](const std::string& why) -> const std::vector<char>* {
-        g_failed[n] = why;
+        g_failed[key] = why;
         if (note) *note = why;
         return nullptr;
     };
     if (!R.ok) return fail("libhiprtc not found");
-    const std::string o_n = "-DFDES_GEN_JIT_N=" + std::to_string(n), o_e = "-DFDES_GEN_JIT_EPT=" + std::to_string(ept_of(n));
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DFDES_TEST_HOOKS=0", o_n.c_str(), o_e.c_str()};
-    const int nopts = (int)(sizeof(opts) / sizeof(opts[0]));
+    const std::string o_n = "-DFDES_GEN_JIT_N=" + std::to_string(n), o_e = "-DFDES_GEN_JIT_EPT=" + std::to_string(ept_of(n, rows)),
+                      o_r = "-DFDES_GEN_JIT_ROWS=" + std::to_string(rows);
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DFDES_TEST_HOOKS=0", o_n.c_str(), o_e.c_str(), o_r.c_str()};
+    const int nopts = (int)(sizeof(opts) / sizeof(opts[0])) - (rows == gen_pass_rows(n) ? 1 : 0); // (the length's own tile rows: no option, and the cache entries of earlier builds stay valid)
     int vmaj = 0, vmin = 0;
     if (R.Version) (void)R.Version(&vmaj, &vmin);
     unsigned long long h = 1469598103934665603ull;
@@ -137,6 +139,7 @@ const std::vector<char>* code_for(int n, std::string* note)
     h = fnv(h, reinterpret_cast<const char*>(&vmin), sizeof(vmin));
     char name[96];
     std::snprintf(name, sizeof(name), "gpass_%d_%016llx.hsaco", n, h);
+    if (rows != gen_pass_rows(n)) std::snprintf(name, sizeof(name), "gpass_%dr%d_%016llx.hsaco", n, rows, h);
     const std::string dir = cache_dir(), path = dir.empty() ? std::string() : dir + "/" + name;
     if (!path.empty()) {
         if (FILE* f = std::fopen(path.c_str(), "rb")) {
@@ -145,7 +148,7 @@ const std::vector<char>* code_for(int n, std::string* note)
             size_t got;
             while ((got = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
             std::fclose(f);
-            if (buf.size() > 64 && !std::memcmp(buf.data(), "\177ELF", 4)) return &(g_code[n] = std::move(buf));
+            if (buf.size() > 64 && !std::memcmp(buf.data(), "\177ELF", 4)) return &(g_code[key] = std::move(buf));
         }
     }
     hiprtcProgram prog = nullptr;
@@ -176,7 +179,7 @@ const std::vector<char>* code_for(int n, std::string* note)
             if (!(okw && okc && std::rename(tmpn.c_str(), path.c_str()) == 0)) (void)std::remove(tmpn.c_str());
         }
     }
-    return &(g_code[n] = std::move(buf));
+    return &(g_code[key] = std::move(buf));
 }
 
 } // namespace
@@ -187,18 +190,20 @@ bool gen_jit_default_on()
     return !(e && e[0] == '0');
 }
 
-const GenJitKernels* gen_jit_prepare(int n, std::string* note)
+const GenJitKernels* gen_jit_prepare(int n, int rows, std::string* note)
 {
-    if (!gen_pass_supported_len(n) || gen_pass_compiled_in(n)) return nullptr;
+    if (!gen_pass_supported_len(n) || !(rows == 2 || rows == 4 || rows == 8) || rows > gen_pass_rows(n)) return nullptr;
+    if (gen_pass_compiled_in(n) && rows == gen_pass_rows(n)) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { if (note) *note = "hipGetDevice failed"; return nullptr; }
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_mod.find({n, dev});
+    auto it = g_mod.find({{n, rows}, dev});
     if (it != g_mod.end()) return it->second;
-    const std::vector<char>* code = code_for(n, note);
+    const std::vector<char>* code = code_for(n, rows, note);
     if (!code) return nullptr;
     GenJitKernels* k = new GenJitKernels();
     k->n = n;
+    k->rows = rows;
     k->device = dev;
     k->threads = 512;
     hipModule_t mod = nullptr;
@@ -224,7 +229,7 @@ const GenJitKernels* gen_jit_prepare(int n, std::string* note)
         (void)hipGetLastError();
         k->fn[i] = fn;
     }
-    g_mod[{n, dev}] = k; // kept until the process ends: plans of any context on this device share it
+    g_mod[{{n, rows}, dev}] = k; // kept until the process ends: plans of any context on this device share it
     return k;
 }
 

@@ -10,7 +10,7 @@ namespace fdes {
 // the compile-time form of fft_gen.hip's passes for ONE row length, compiled by hipRTC and loaded on one device
 struct GenJitKernels {
     static constexpr int kCount = 16; // the pass kinds of gen_pass()
-    int n = 0, device = 0, threads = 512;
+    int n = 0, rows = 0, device = 0, threads = 512; // row length, rows per tile it was compiled for
     void* module = nullptr;           // hipModule_t
     void* fn[kCount] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -18,9 +18,9 @@ struct GenJitKernels {
 // FDES_JIT != "0"
 bool gen_jit_default_on();
 // The kernels of the n-point passes on the CURRENT device: from this process, from the directory cache, or compiled now (seconds).
-// nullptr: n has compiled-in kernels or is no mixed-radix length (note stays empty), or hipRTC is missing / the compilation
+// nullptr: n has compiled-in kernels (for these tile rows) or is no mixed-radix length (note stays empty), or hipRTC is missing / the compilation
 // failed (note says why; the run-time-length kernels serve the length).  Call at plan creation, never inside a stream capture.
-const GenJitKernels* gen_jit_prepare(int n, std::string* note);
+const GenJitKernels* gen_jit_prepare(int n, int rows, std::string* note); // rows: gen_pass_tile_rows(n, rows of the grid)
 // hipFunction_t of one pass kind, nullptr if there is none
 void* gen_jit_function(const GenJitKernels* k, int pre, int mid, int post, bool store_transposed);
 

@@ -173,8 +173,8 @@ int forward_propagation(fdes_plan* pl, int comp)
 //   P6  F[kx][y]       -FFT_y, * P, IFFT_y->             PSIH[y][kx]
 // pass over the rows of an "N" grid ([y][kx], row length m1) with a transposed store into a "T" grid, and the reverse;
 // callers whose input or output is a dense natural grid (PSI, T, user buffers) override the pitch with 0
-PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.jit = pl->fft->jit_x; a.nrows = pl->p.m2; a.wg = pl->wg; a.pitch_in = pl->pitchN; a.pitch_out = pl->pitchT; a.walk = owner_ctx(pl)->walk; a.stagger = owner_ctx(pl)->stagger; return a; }
-PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.jit = pl->fft->jit_y; a.nrows = pl->p.m1; a.wg = pl->wg; a.pitch_in = pl->pitchT; a.pitch_out = pl->pitchN; a.walk = owner_ctx(pl)->walk; a.stagger = owner_ctx(pl)->stagger; return a; }
+PassArgs pass_x(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0x; a.tw1 = pl->fft->tw1x; a.jit = pl->fft->jit_x; a.tile_rows = pl->fft->rows_x; a.nrows = pl->p.m2; a.wg = pl->wg; a.pitch_in = pl->pitchN; a.pitch_out = pl->pitchT; a.walk = owner_ctx(pl)->walk; a.stagger = owner_ctx(pl)->stagger; return a; }
+PassArgs pass_y(fdes_plan* pl) { PassArgs a; a.tw0 = pl->fft->tw0y; a.tw1 = pl->fft->tw1y; a.jit = pl->fft->jit_y; a.tile_rows = pl->fft->rows_y; a.nrows = pl->p.m1; a.wg = pl->wg; a.pitch_in = pl->pitchT; a.pitch_out = pl->pitchN; a.walk = owner_ctx(pl)->walk; a.stagger = owner_ctx(pl)->stagger; return a; }
 
 // stream of the potential / transmission passes
 hipStream_t vstream(fdes_plan* pl) { return (pl->split && !pl->tap_mode) ? pl->vs : pl->ctx->stream; }

@@ -163,3 +163,53 @@ def test_run_time_compiled_kernels_whole_driver_and_mixed_axes(oracle, tmp_path,
         ref = np.fft.ifft2(f.astype(np.complex128)) * f.size if inv else np.fft.fft2(f.astype(np.complex128))
         assert relerr(o, ref) < 6e-7
     eng.close()
+
+
+@pytest.mark.parametrize("m,nz,jit", [(750, 2, 0), (750, 1, 1), (500, 1, 0), (500, 2, 1), (1250, 1, 1)])
+def test_grids_that_the_tile_rows_do_not_divide(oracle, tmp_path, monkeypatch, m, nz, jit):
+    """A mixed-radix row length has tiles of 8 (up to 512 points), 4 (up to 2048) or 2 rows; until round 5 a grid whose other
+    dimension that number does not divide left the fused loop (750^2 and 1250^2: m = 2 nx of a .qsc with an odd nx,
+    src/rwQsc.cu:943-948; 500^2).  Such grids now run smaller tiles (gen_pass_tile_rows: 750 -> 2 rows, 500 -> 4) on the
+    run-time-length kernels resp. on kernels compiled for the length AND the tile rows (500 has compiled-in kernels for 8-row
+    tiles only): slice loop and potential against the float64 oracle, with and without the empty-slice short cut."""
+    monkeypatch.setenv("FDES_JIT_CACHE", str(tmp_path / "jit"))
+    hp, at = S.case_tiny(m=m, m3=5, nz=nz, nat=300, tilt=True, seed=71 + nz)
+    fdes_amd.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    ref = oracle.wave(q, at, 0, 0, prec="f64")
+    r32 = oracle.wave(q, at, 0, 0, prec="f32")
+    assert fdes_amd.load_library().fdes_grid_backend(m, m, 0) == 2
+    for skip in (0, 1):
+        eng = fdes_amd.Engine(0, skip_empty=skip, jit=jit)
+        pl = eng.plan(hp, at)
+        assert pl.fft_backend() == 2 and pl.jit_kernels() == (2 if jit else 0)
+        psi = pl.tap_wave(0, 0)
+        check(psi, ref, r32, 1e-5, f"{m}^2 on smaller tiles, nz={nz} jit={jit} skip_empty={skip}")
+        if skip == 0:
+            xyz = oracle.config_coords(q, at, 0, -1)
+            V = pl.tap_potential(0, 0, 3)
+            check(V, oracle.phase_grating(q, at, xyz, 3, "f64"), None, 1e-5, f"{m}^2 on smaller tiles, potential s=3 nz={nz} jit={jit}")
+        pl.close()
+        eng.close()
+    if jit:
+        assert any(f"gpass_{m}r" in p.name for p in (tmp_path / "jit").iterdir())
+
+
+def test_smaller_tiles_whole_driver_and_fft(oracle, engine):
+    """Frozen-phonon image through the whole driver (lanes, gangs, graph replay) on a 750^2 grid (two-row tiles) against the
+    float32 oracle; the 2-D FFT alone at 1430 x 2002 (neither length's four-row tiles divide the other dimension) against numpy."""
+    hp, at = S.case_tiny(m=750, m3=6, nz=2, frPh=3, nat=200, tilt=True)
+    fdes_amd.consistent(hp)
+    eng = fdes_amd.Engine(0)
+    img = eng.build_measurements(hp, at)["image"]
+    eng.close()
+    e = relerr(img, oracle.build_measurements(hp, at, prec="f32")["image"])
+    print(f"[parity] driver 750^2 frPh=3 on two-row tiles: E = {e:.3e}")
+    assert e <= 1e-5
+    rng = np.random.default_rng(3)
+    f = (rng.standard_normal((2002, 1430)) + 1j * rng.standard_normal((2002, 1430))).astype(np.complex64)
+    for inv in (False, True):
+        o, used = engine.fft2(f, inv, backend=2)
+        assert used == 2
+        ref = np.fft.ifft2(f.astype(np.complex128)) * f.size if inv else np.fft.fft2(f.astype(np.complex128))
+        assert relerr(o, ref) < 6e-7
