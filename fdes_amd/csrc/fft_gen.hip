@@ -1313,10 +1313,6 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
         if (n == 3200) return gdispatch<3200, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
         if (n == 3600) return gdispatch<3600, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
         if (n == 4000) return gdispatch<4000, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
-#ifdef FDES_GEN_EXTRA_A // experiment: what would a compile-time kernel buy for a length that has none? (-DFDES_GEN_EXTRA_A=1100 -DFDES_GEN_EXTRA_B=2288)
-        if (n == FDES_GEN_EXTRA_A) return gdispatch<FDES_GEN_EXTRA_A, (FDES_GEN_EXTRA_A <= 1024 ? 8 : 16)>(pre, mid, post, st_t, a, f, st);
-        if (n == FDES_GEN_EXTRA_B) return gdispatch<FDES_GEN_EXTRA_B, (FDES_GEN_EXTRA_B <= 1024 ? 8 : 16)>(pre, mid, post, st_t, a, f, st);
-#endif
     }
     if (ept <= 8) return gdispatch<0, 8>(pre, mid, post, st_t, a, f, st);
     if (ept <= 16) return gdispatch<0, 16>(pre, mid, post, st_t, a, f, st);
