@@ -288,7 +288,11 @@ int fdes_plan_slice_loop_ms(fdes_plan* plan, double* total_ms, int64_t* slices);
  *                -1 .. -2048 (experiment, round 5): the first generation of workgroups on the odd CUs starts |value| x 64
  *                cycles late (the CUs of the chip in different phases; measured without effect, profiles/r05_cu_class_stagger_4096.txt)
  *   "peer_copy"  1 (default): fdes_plan_accumulate_from moves a partial sum between GPUs by a peer copy and falls back
- *                to host staging when the runtime refuses it; 0: always stage through host memory                 */
+ *                to host staging when the runtime refuses it; 0: always stage through host memory
+ *   "jit"        -1 (default): unless FDES_JIT=0, a plan on the fused loop whose grid length has no compiled-in mixed-radix
+ *                kernels (for its tile rows) gets them compiled by hipRTC when it is created (seconds once per length and
+ *                machine: directory cache FDES_JIT_CACHE, else ~/.cache/fdes_amd); 1: always, 0: never - the kernels that take
+ *                the length at run time serve then, and whenever libhiprtc is missing (fdes_plan_jit_kernels tells)  */
 int fdes_set_option(fdes_ctx* ctx, const char* key, int64_t value);
 
 /* Progress report.  The reference prints a percentage to stderr from inside its slice loop (progressCounter,
