@@ -21,6 +21,7 @@
 #ifndef __HIPCC_RTC__
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #include "gen_jit.h"
@@ -1269,7 +1270,12 @@ int gen_pass_rows(int n) { return gen_rows(n); }
 // of a .qsc with an odd nx) two-row tiles instead of leaving the fused loop; 0: nrows is odd
 int gen_pass_tile_rows(int n, int nrows)
 {
-    for (int r = gen_rows(n); r >= 2; r >>= 1)
+    int r0 = gen_rows(n);
+    if (const char* e = std::getenv("FDES_GEN_TILE_ROWS")) { // measurement knob: smaller tiles where the default would do (profiles/r05_smaller_tiles.txt)
+        const int v = std::atoi(e);
+        if ((v == 2 || v == 4) && v < r0) r0 = v;
+    }
+    for (int r = r0; r >= 2; r >>= 1)
         if (nrows % r == 0) return r;
     return 0;
 }
