@@ -103,6 +103,7 @@ void make_dirs(const std::string& d)
 
 std::mutex g_mu;
 std::map<std::pair<int, int>, std::vector<char>> g_code;        // (length, tile rows) -> code object (compiled or read from the cache once per process)
+std::map<std::pair<int, int>, std::string> g_from_file;         // (length, tile rows) -> cache file the code object was READ from (not compiled in this process)
 std::map<std::pair<int, int>, std::string> g_failed;            // (length, tile rows) -> why it has no code object (not tried again)
 std::map<std::pair<std::pair<int, int>, int>, GenJitKernels*> g_mod; // ((length, tile rows), device) -> loaded module
 
@@ -138,9 +139,11 @@ const std::vector<char>* code_for(int n, int rows, std::string* note)
     h = fnv(h, reinterpret_cast<const char*>(&vmaj), sizeof(vmaj));
     h = fnv(h, reinterpret_cast<const char*>(&vmin), sizeof(vmin));
     char name[96];
-    std::snprintf(name, sizeof(name), "gpass_%d_%016llx.hsaco", n, h);
-    if (rows != gen_pass_rows(n)) std::snprintf(name, sizeof(name), "gpass_%dr%d_%016llx.hsaco", n, rows, h);
+    std::snprintf(name, sizeof(name), "gpass_%d_%016llx.bin", n, h);
+    if (rows != gen_pass_rows(n)) std::snprintf(name, sizeof(name), "gpass_%dr%d_%016llx.bin", n, rows, h);
     const std::string dir = cache_dir(), path = dir.empty() ? std::string() : dir + "/" + name;
+    // cache file = "FDESJIT1", length of the code object, its FNV-1a hash, the code object: a file cut short (a full disk, a
+    // killed process of an older build without the rename) must never reach hipModuleLoadData, which does not survive one
     if (!path.empty()) {
         if (FILE* f = std::fopen(path.c_str(), "rb")) {
             std::vector<char> buf;
@@ -148,7 +151,17 @@ const std::vector<char>* code_for(int n, int rows, std::string* note)
             size_t got;
             while ((got = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
             std::fclose(f);
-            if (buf.size() > 64 && !std::memcmp(buf.data(), "\177ELF", 4)) return &(g_code[key] = std::move(buf));
+            unsigned long long len = 0, sum = 0;
+            if (buf.size() > 24 + 64 && !std::memcmp(buf.data(), "FDESJIT1", 8)) {
+                std::memcpy(&len, buf.data() + 8, 8);
+                std::memcpy(&sum, buf.data() + 16, 8);
+            }
+            if (len != 0 && len == buf.size() - 24 && sum == fnv(1469598103934665603ull, buf.data() + 24, (size_t)len) && !std::memcmp(buf.data() + 24, "\177ELF", 4)) {
+                buf.erase(buf.begin(), buf.begin() + 24);
+                g_from_file[key] = path;
+                return &(g_code[key] = std::move(buf));
+            }
+            (void)std::remove(path.c_str()); // not ours or damaged: compiled again below
         }
     }
     hiprtcProgram prog = nullptr;
@@ -174,7 +187,9 @@ const std::vector<char>* code_for(int n, int rows, std::string* note)
         make_dirs(dir);
         const std::string tmpn = path + "." + std::to_string((long)getpid()) + ".tmp";
         if (FILE* f = std::fopen(tmpn.c_str(), "wb")) {
-            const bool okw = std::fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+            const unsigned long long len = buf.size(), sum = fnv(1469598103934665603ull, buf.data(), buf.size());
+            bool okw = std::fwrite("FDESJIT1", 1, 8, f) == 8 && std::fwrite(&len, 1, 8, f) == 8 && std::fwrite(&sum, 1, 8, f) == 8;
+            okw = okw && std::fwrite(buf.data(), 1, buf.size(), f) == buf.size();
             const bool okc = std::fclose(f) == 0;
             if (!(okw && okc && std::rename(tmpn.c_str(), path.c_str()) == 0)) (void)std::remove(tmpn.c_str());
         }
@@ -207,8 +222,21 @@ const GenJitKernels* gen_jit_prepare(int n, int rows, std::string* note)
     k->device = dev;
     k->threads = 512;
     hipModule_t mod = nullptr;
-    if (hipModuleLoadData(&mod, code->data()) != hipSuccess) {
+    hipError_t le = hipModuleLoadData(&mod, code->data());
+    if (le != hipSuccess) {
         (void)hipGetLastError();
+        auto ff = g_from_file.find({n, rows});
+        if (ff != g_from_file.end()) { // a cache file that does not load (truncated by a full disk, written by another runtime): drop it and compile once
+            (void)std::remove(ff->second.c_str());
+            g_from_file.erase(ff);
+            g_code.erase({n, rows});
+            code = code_for(n, rows, note);
+            mod = nullptr;
+            le = code ? hipModuleLoadData(&mod, code->data()) : hipErrorUnknown;
+            if (le != hipSuccess) (void)hipGetLastError();
+        }
+    }
+    if (le != hipSuccess) {
         delete k;
         if (note) *note = "hipModuleLoadData failed for the " + std::to_string(n) + "-point passes";
         return nullptr;

@@ -121,7 +121,7 @@ def test_run_time_compiled_kernels_against_oracle(oracle, tmp_path, monkeypatch)
         assert relerr(waves[1], waves[0]) < 2e-6
     cached = sorted(p.name for p in (tmp_path / "jit").iterdir())
     assert len(cached) == 2 and cached[0].startswith("gpass_1100_") and cached[1].startswith("gpass_572_"), cached
-    assert all((tmp_path / "jit" / n).read_bytes()[:4] == b"\x7fELF" for n in cached)
+    assert all((tmp_path / "jit" / n).read_bytes()[:8] == b"FDESJIT1" and (tmp_path / "jit" / n).read_bytes()[24:28] == b"\x7fELF" for n in cached)
 
 
 def test_run_time_compiled_kernels_whole_driver_and_mixed_axes(oracle, tmp_path, monkeypatch):
@@ -213,3 +213,38 @@ def test_smaller_tiles_whole_driver_and_fft(oracle, engine):
         assert used == 2
         ref = np.fft.ifft2(f.astype(np.complex128)) * f.size if inv else np.fft.fft2(f.astype(np.complex128))
         assert relerr(o, ref) < 6e-7
+
+
+_JIT_CACHE_PROBE = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import fdes_amd
+from tests import specimens as S
+hp, at = S.case_tiny(m=572, m3=2, nz=1, nat=20)
+fdes_amd.consistent(hp)
+eng = fdes_amd.Engine(0, jit=1)
+pl = eng.plan(hp, at)
+print("axes", pl.jit_kernels())
+pl.close(); eng.close()
+'''
+
+
+def test_run_time_compilation_cache_survives_a_damaged_file(tmp_path):
+    """The code objects of the run-time compilation live in a directory cache.  A second process reads what the first one wrote
+    (no compilation: the file is untouched); a file cut short (a full disk) fails its length / checksum header,
+    never reaches the module loader (which does not survive a truncated code object), and is compiled and cached again."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FDES_JIT_CACHE=str(tmp_path / "jit"), FDES_JIT="1")
+    def run():
+        r = subprocess.run([sys.executable, "-c", _JIT_CACHE_PROBE, root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "axes 2" in r.stdout, r.stdout + r.stderr
+    run()
+    files = list((tmp_path / "jit").iterdir())
+    assert len(files) == 1 and files[0].stat().st_size > 10000
+    stamp = files[0].stat().st_mtime_ns
+    run()
+    assert files[0].stat().st_mtime_ns == stamp          # read, not rewritten
+    files[0].write_bytes(files[0].read_bytes()[:4096])
+    run()
+    assert files[0].stat().st_size > 10000               # dropped, compiled again, cached again
