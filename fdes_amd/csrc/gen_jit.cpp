@@ -8,7 +8,7 @@
 // against 6.4 k, profiles/r05_radix_11_13.txt).  Here the compile-time form of ANY supported length is built when a plan for
 // it is created: the library carries the text of fft_gen.hip and its three includes (gen_jit_src.inc, written by the
 // Makefile), hipRTC compiles it with -DFDES_GEN_JIT_N=<n> (about five seconds), the code object is kept in a directory cache
-// ($FDES_JIT_CACHE, else $XDG_CACHE_HOME/fdes_amd, else ~/.cache/fdes_amd; keyed on the source text, the options and the hipRTC version), loaded as a module on the plan's
+// ($FDES_JIT_CACHE, else $XDG_CACHE_HOME/fdes_amd, else ~/.cache/fdes_amd; keyed on the source text, the options and the hipRTC version; every file carries the length and a checksum of its code object and is ignored when they do not match), loaded as a module on the plan's
 // device, and gen_pass() launches its kernels through hipModuleLaunchKernel.  libhiprtc is resolved with dlopen: without it, or
 // when the compilation fails, the plan runs the run-time-length kernels as before (the reason is kept for the caller).
 // FDES_JIT=0 (or engine option jit = 0) turns it off.
