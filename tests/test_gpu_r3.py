@@ -149,7 +149,7 @@ def test_wave_passes_equal_lanes_graph_and_empty_slices(oracle, threads):
 @pytest.mark.parametrize("shape", [(320, 320), (800, 800), (1000, 1000), (1000, 512), (640, 960), (1280, 1500), (2000, 1920),
                                    (3000, 3000), (2560, 3072), (3600, 4000), (3200, 4096), (2048, 2560), (2304, 2700), (1600, 1280),
                                    (448, 896), (1400, 1792), (2016, 3584), (1372, 1024),   # 7-smooth lengths (radix 7); 1372 = 4 * 7^3   # (round 4: lengths beyond 2048; 2304 x 2700: run-time-length kernels there)
-                                   (1100, 572), (1144, 2600), (3300, 2860), (2288, 1716)])   # round 5: radix 11 and 13 (1100 = 2 nx of a .qsc with nx = 550; 572 = 4 * 11 * 13, 1716 = 4 * 3 * 11 * 13, 2288 = 16 * 11 * 13; two-row tiles beyond 2048)
+                                   (1100, 572), pytest.param((1144, 2600), marks=full_only), pytest.param((3300, 2860), marks=full_only), (2288, 1716)])   # round 5: radix 11 and 13 (1100 = 2 nx of a .qsc with nx = 550; 572 = 4 * 11 * 13, 1716 = 4 * 3 * 11 * 13, 2288 = 16 * 11 * 13; two-row tiles beyond 2048)
 def test_mixed_radix_fft_against_numpy(engine, shape):
     """Row FFTs of length 2^a 3^b 5^c 7^d 11^e 13^f (Stockham stages of radix 13, 11, 10, 8, 7, 5, 4, 3, 2 in LDS) as a 2-D transform against
     numpy, also paired with a power-of-two length (cufftPlan2d serves any size, src/paramStructure.cu:676-679)."""

@@ -5,6 +5,7 @@ import pytest
 import fdes_amd
 from tests import specimens as S
 from tests.test_gpu_parity import check, relerr
+from tests.conftest import full_only
 
 pytestmark = pytest.mark.gpu
 
@@ -165,7 +166,7 @@ def test_run_time_compiled_kernels_whole_driver_and_mixed_axes(oracle, tmp_path,
     eng.close()
 
 
-@pytest.mark.parametrize("m,nz,jit", [(750, 2, 0), (750, 1, 1), (500, 1, 0), (500, 2, 1), (1250, 1, 1)])
+@pytest.mark.parametrize("m,nz,jit", [(750, 2, 0), pytest.param(750, 1, 1, marks=full_only), pytest.param(500, 1, 0, marks=full_only), (500, 2, 1), (1250, 1, 1)])
 def test_grids_that_the_tile_rows_do_not_divide(oracle, tmp_path, monkeypatch, m, nz, jit):
     """A mixed-radix row length has tiles of 8 (up to 512 points), 4 (up to 2048) or 2 rows; until round 5 a grid whose other
     dimension that number does not divide left the fused loop (750^2 and 1250^2: m = 2 nx of a .qsc with an odd nx,
