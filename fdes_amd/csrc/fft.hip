@@ -49,13 +49,10 @@ int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err, b
     m1 = m1_;
     m2 = m2_;
     const bool lds_ok = lds_supported(m1, m2);
-    if (opt == 2 && !lds_ok) { if (err) *err = "hand-written FFT needs grid lengths 256 ... 4096 that are powers of two, or 2^a 3^b 5^c 7^d 11^e 13^f up to 4096 (a multiple of the tile rows: 4, two beyond 2048 points)"; return -1; }
+    if (opt == 2 && !lds_ok) { if (err) *err = "hand-written FFT needs grid lengths 256 ... 4096 that are powers of two, or even 2^a 3^b 5^c 7^d 11^e 13^f lengths up to 8192 (beyond 4096 points with run-time compilation only)"; return -1; }
     backend = (opt == 1 || !lds_ok) ? 1 : 2;
     if (backend == 2) {
         wg = pick_wg(m1, m2);
-        if (upload_twiddles(m1, &tw0x, &tw1x, st, err)) return -1;
-        if (upload_twiddles(m2, &tw0y, &tw1y, st, err)) return -1;
-        if (hipMalloc((void**)&scratch, sizeof(float2) * (size_t)m1 * m2) != hipSuccess) { if (err) *err = "scratch allocation failed"; return -1; }
         // mixed-radix axes: tiles smaller than the length's own where those do not divide the other dimension
         rows_x = gen_pass_supported_len(m1) ? gen_pass_tile_rows(m1, m2) : 0;
         rows_y = gen_pass_supported_len(m2) ? gen_pass_tile_rows(m2, m1) : 0;
@@ -64,6 +61,18 @@ int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err, b
             jit_y = (m2 == m1) ? jit_x : gen_jit_prepare(m2, rows_y, &jit_note);
             if (!jit_note.empty() && std::getenv("FDES_JIT_VERBOSE")) std::fprintf(stderr, "  FDES: run-time-length kernels (%s)\n", jit_note.c_str());
         }
+        // rows beyond 4096 points exist as compiled kernels only: without them the grid takes rocFFT like any unsupported size
+        if ((m1 > 4096 && rows_x > 0 && !jit_x) || (m2 > 4096 && rows_y > 0 && !jit_y)) {
+            if (opt == 2) { if (err) *err = "rows beyond 4096 points need their kernels compiled at plan creation (hipRTC; option jit, FDES_JIT): " + jit_note; return -1; }
+            backend = 1;
+            jit_x = jit_y = nullptr;
+            rows_x = rows_y = 0;
+        }
+    }
+    if (backend == 2) {
+        if (upload_twiddles(m1, &tw0x, &tw1x, st, err)) return -1;
+        if (upload_twiddles(m2, &tw0y, &tw1y, st, err)) return -1;
+        if (hipMalloc((void**)&scratch, sizeof(float2) * (size_t)m1 * m2) != hipSuccess) { if (err) *err = "scratch allocation failed"; return -1; }
         return 0;
     }
     const size_t lengths[2] = {(size_t)m1, (size_t)m2}; // rocFFT: lengths[0] is the fastest dimension

@@ -39,6 +39,7 @@ namespace {
 
 #include "fft_dev.inc"
 
+constexpr int kGenMaxLen = 8192; // longest row: a tile of two rows (one image) is 128 KiB of LDS
 constexpr int kRxMax = 13; // largest radix of a stage: registers of one butterfly (run-time-length kernels)
 
 struct GenFac {
@@ -119,6 +120,30 @@ __host__ __device__ constexpr bool gen_auto_three_stages(int n, int (&r)[3])
     return best >= 0;
 }
 
+// the same with FOUR stages for the lengths three cannot serve (8192 = 16 x 16 x 8 x 4, 6144, 7168 ...: rows beyond 4096 points,
+// run-time compilation only): smallest largest radix, odd first radix where one exists, then the larger second radix
+__host__ __device__ constexpr bool gen_auto_four_stages(int n, int (&r)[4])
+{
+    const int S[14] = {25, 20, 16, 15, 13, 12, 11, 10, 8, 7, 5, 4, 3, 2};
+    long best = -1;
+    for (int ia = 0; ia < 14; ia++)
+        for (int ib = 0; ib < 14; ib++)
+            for (int ic = 0; ic < 14; ic++) {
+                const int a = S[ia], b = S[ib], c = S[ic];
+                if (n % (a * b * c) != 0) continue;
+                const int d = n / (a * b * c);
+                bool ok = false;
+                for (int id = 0; id < 14; id++) ok = ok || S[id] == d;
+                if (!ok) continue;
+                int mx = a > b ? a : b;
+                mx = mx > c ? mx : c;
+                mx = mx > d ? mx : d;
+                const long score = (long)(64 - mx) * 1000000 + (long)((a % 2 == 1) ? 100 + a : (a == 16 ? 0 : 50 - a)) * 1000 + b * 30 + c;
+                if (score > best) { best = score; r[0] = a; r[1] = b; r[2] = c; r[3] = d; }
+            }
+    return best >= 0;
+}
+
 // factors and stage tables of an n-point row; false if n has a prime factor above 13 or more than 8 stages
 __host__ __device__ constexpr bool factorize(int n, GenFac& f)
 {
@@ -155,10 +180,13 @@ __host__ __device__ constexpr bool factorize(int n, GenFac& f)
 #ifdef FDES_GEN_JIT_N
     {   // run-time compilation of ONE length (gen_jit.cpp): three stages with composite radices where the single radices need more,
         // chosen as the hand-measured table above suggests (gen_auto_three_stages)
-        int cr[3] = {0, 0, 0};
+        int cr[3] = {0, 0, 0}, c4[4] = {0, 0, 0, 0};
         if (n == FDES_GEN_JIT_N && n > 512 && f.nf > 3 && gen_auto_three_stages(n, cr)) {
             f.nf = 3;
             for (int q = 0; q < 8; q++) f.radix[q] = q < 3 ? cr[q] : 0;
+        } else if (n == FDES_GEN_JIT_N && n > 4096 && f.nf > 4 && gen_auto_four_stages(n, c4)) {
+            f.nf = 4;
+            for (int q = 0; q < 8; q++) f.radix[q] = q < 4 ? c4[q] : 0;
         }
     }
 #endif
@@ -1113,7 +1141,7 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
 }
 // waves per SIMD the register allocation is held to: EPT <= 8 (rows up to 1024 points) and the one-image kernels: two workgroups
 // per CU (the species loop of MID_GTABN needs more than 128 registers)
-#define FDES_GPASS_BOUNDS(NC, EPT, MID) __launch_bounds__(fdes::gen_threads(NC), ((((EPT) <= 8 || ((NC) != 0 && fdes::gen_one_image(NC))) && (MID) != fdes::MID_GTABN) ? 4 : 2))
+#define FDES_GPASS_BOUNDS(NC, EPT, MID) __launch_bounds__(fdes::gen_threads(NC), ((((EPT) <= 8 || ((NC) != 0 && fdes::gen_one_image(NC))) && (MID) != fdes::MID_GTABN && (NC) <= 4096) ? 4 : 2)) // (rows beyond 4096 points: a tile of two rows is 80 ... 128 KiB, one workgroup per CU may use 256 registers)
 template <int NC, int EPT, int PRE, int MID, int POST, bool STORE_T>
 __global__ FDES_GPASS_BOUNDS(NC, EPT, MID) void k_gpass(PassArgs A, GenFac Frt)
 {
@@ -1259,7 +1287,11 @@ template <int NC, int EPT> hipError_t gdispatch(int pre, int mid, int post, bool
 
 bool gen_pass_supported_len(int n)
 {
-    if (n < 256 || n > 4096) return false;
+    if (n > 4096) { // rows of 4098 ... 8192 points (round 5): one tile image of two rows, compile-time kernels only - i.e. compiled at plan creation
+        GenFac f8;
+        return n <= kGenMaxLen && n % 2 == 0 && gen_jit_available() && factorize(n, f8);
+    }
+    if (n < 256) return false;
     if ((n & (n - 1)) == 0) return false; // powers of two have kernels of their own
     GenFac f;
     return factorize(n, f);
@@ -1293,7 +1325,7 @@ void gen_pass_twiddles(int n, float* tw)
 hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs& a, hipStream_t st)
 {
     GenFac f;
-    if (!gen_pass_supported_len(n) || !factorize(n, f)) return hipErrorInvalidValue;
+    if (!factorize(n, f) || n < 256 || n > kGenMaxLen) return hipErrorInvalidValue; // (gen_pass_supported_len was asked when the plan was made)
     f.rows = (a.tile_rows == 2 || a.tile_rows == 4 || a.tile_rows == 8) && a.tile_rows <= gen_rows(n) ? a.tile_rows : gen_rows(n);
     f.lrows = gen_lrows(f.rows);
     const int ept = (f.rows * n + kGenThreads - 1) / kGenThreads;
@@ -1320,6 +1352,7 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
         if (n == 3600) return gdispatch<3600, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
         if (n == 4000) return gdispatch<4000, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
     }
+    if (n > 4096) return hipErrorInvalidValue; // (rows beyond 4096 points have no run-time-length form: Fft2D::create takes rocFFT when their compilation fails)
     if (ept <= 8) return gdispatch<0, 8>(pre, mid, post, st_t, a, f, st);
     if (ept <= 16) return gdispatch<0, 16>(pre, mid, post, st_t, a, f, st);
     return hipErrorInvalidValue;

@@ -17,6 +17,9 @@ struct GenJitKernels {
 
 // FDES_JIT != "0"
 bool gen_jit_default_on();
+// libhiprtc can be loaded: grid lengths beyond 4096 points exist on the fused loop only then (they have no other kernels), and only for
+// plans that ask for the compilation (option jit / FDES_JIT)
+bool gen_jit_available();
 // The kernels of the n-point passes on the CURRENT device: from this process, from the directory cache, or compiled now (seconds).
 // nullptr: n has compiled-in kernels (for these tile rows) or is no mixed-radix length (note stays empty), or hipRTC is missing / the compilation
 // failed (note says why; the run-time-length kernels serve the length).  Call at plan creation, never inside a stream capture.

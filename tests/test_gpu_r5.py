@@ -249,3 +249,45 @@ def test_run_time_compilation_cache_survives_a_damaged_file(tmp_path):
     files[0].write_bytes(files[0].read_bytes()[:4096])
     run()
     assert files[0].stat().st_size > 10000               # dropped, compiled again, cached again
+
+
+@pytest.mark.parametrize("m1,m2", [(8192, 256), (256, 6144), (4800, 500)])
+def test_rows_beyond_4096_points(oracle, tmp_path, monkeypatch, m1, m2):
+    """Grid lengths of 4098 ... 8192 points (even, 2^a 3^b 5^c 7^d 11^e 13^f; cufftPlan2d serves any size alike,
+    src/paramStructure.cu:676-679) run the fused loop on kernels compiled at plan creation - one tile image of two rows, three
+    or four stages (8192 = 16 x 16 x 8 x 4) - instead of the rocFFT + point-wise loop; with jit = 0 they take rocFFT as before.
+    Rectangular grids keep the oracle cheap: 2-D FFT against numpy, slice loop and potential against the float64 oracle."""
+    monkeypatch.setenv("FDES_JIT_CACHE", str(tmp_path / "jit"))
+    rng = np.random.default_rng(11)
+    f = (rng.standard_normal((m2, m1)) + 1j * rng.standard_normal((m2, m1))).astype(np.complex64)
+    eng = fdes_amd.Engine(0, jit=1)
+    for inv in (False, True):
+        o, used = eng.fft2(f, inv, backend=0)
+        assert used == 2
+        ref = np.fft.ifft2(f.astype(np.complex128)) * f.size if inv else np.fft.fft2(f.astype(np.complex128))
+        e = relerr(o, ref)
+        print(f"[parity] fft {m1} x {m2} inv={inv}: rel L2 {e:.3e}")
+        assert e < 7e-7
+    eng.close()
+    hp, at = S.case_tiny(m=m1, m2=m2, m3=3, nz=2, nat=150, tilt=True, seed=23)
+    fdes_amd.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    ref = oracle.wave(q, at, 0, 0, prec="f64")
+    r32 = oracle.wave(q, at, 0, 0, prec="f32")
+    for skip in (0, 1):
+        eng = fdes_amd.Engine(0, skip_empty=skip, jit=1)
+        pl = eng.plan(hp, at)
+        assert pl.fft_backend() == 2 and pl.jit_kernels() >= 1
+        psi = pl.tap_wave(0, 0)
+        check(psi, ref, r32, 1e-5, f"rows beyond 4096 points, {m1} x {m2} skip_empty={skip}")
+        if skip == 0:
+            xyz = oracle.config_coords(q, at, 0, -1)
+            V = pl.tap_potential(0, 0, 1)
+            check(V, oracle.phase_grating(q, at, xyz, 1, "f64"), None, 1e-5, f"rows beyond 4096 points, potential s=1 {m1} x {m2}")
+        pl.close()
+        eng.close()
+    eng = fdes_amd.Engine(0, jit=0)
+    pl = eng.plan(hp, at)
+    assert pl.fft_backend() == 1 and pl.jit_kernels() == 0      # no kernels without the compilation: rocFFT, as every unsupported size
+    pl.close()
+    eng.close()

@@ -110,7 +110,7 @@ def test_mixed_radix_source_compiles_under_hiprtc(n, ept):
 def test_which_grids_run_the_fused_loop():
     """fdes_grid_backend (host only): powers of two and lengths 2^a 3^b 5^c 7^d 11^e 13^f in [256, 4096] run the fused loop (2) -
     also where the tile rows of a mixed-radix length (8 up to 512 points, 4 up to 2048) do not divide the other dimension: smaller
-    tiles then (500^2; 750^2 = 2 nx of a .qsc with an odd nx); a prime factor above 13, an odd length, a length beyond 4096, or a
+    tiles then (500^2; 750^2 = 2 nx of a .qsc with an odd nx); a prime factor above 13, an odd length, a length beyond 8192, or a
     mixed-radix length beside a power of two whose row group does not divide it stay on rocFFT (1), as does option fft = 1."""
     lib = fdes_amd.load_library()
     for m in (256, 320, 500, 572, 750, 800, 1000, 1100, 1250, 1430, 2002, 2048, 2288, 3000, 3300, 4000, 4096):
@@ -119,6 +119,14 @@ def test_which_grids_run_the_fused_loop():
         assert lib.fdes_grid_backend(m, m, 0) == 1, m
     assert lib.fdes_grid_backend(450, 4096, 0) == 2 and lib.fdes_grid_backend(500, 512, 0) == 2 and lib.fdes_grid_backend(1100, 572, 0) == 2
     assert lib.fdes_grid_backend(750, 1024, 0) == 1 and lib.fdes_grid_backend(1000, 1000, 1) == 1
+    # rows of 4098 ... 8192 points exist as kernels compiled at plan creation only: fused (2) where that is not turned off
+    # (this suite runs with FDES_JIT=0, tests/conftest.py: the query says 1 here) and libhiprtc loads
+    code = ("import sys; sys.path.insert(0, %r); import fdes_amd\n"
+            "lib = fdes_amd.load_library()\n"
+            "print([lib.fdes_grid_backend(m, m, 0) for m in (8192, 5000, 6144, 4100, 8194, 9000)], lib.fdes_grid_backend(8192, 256, 0))\n" % ROOT)
+    for jit, want in (("0", "[1, 1, 1, 1, 1, 1] 1"), ("1", "[2, 2, 2, 1, 1, 1] 2")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDES_JIT=jit), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and want in r.stdout, (jit, r.stdout, r.stderr)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
