@@ -251,7 +251,7 @@ def test_run_time_compilation_cache_survives_a_damaged_file(tmp_path):
     assert files[0].stat().st_size > 10000               # dropped, compiled again, cached again
 
 
-@pytest.mark.parametrize("m1,m2", [(8192, 256), (256, 6144), (4800, 500)])
+@pytest.mark.parametrize("m1,m2", [(8192, 256), (256, 6144), (4800, 500), pytest.param(5000, 5000, marks=full_only)])
 def test_rows_beyond_4096_points(oracle, tmp_path, monkeypatch, m1, m2):
     """Grid lengths of 4098 ... 8192 points (even, 2^a 3^b 5^c 7^d 11^e 13^f; cufftPlan2d serves any size alike,
     src/paramStructure.cu:676-679) run the fused loop on kernels compiled at plan creation - one tile image of two rows, three
