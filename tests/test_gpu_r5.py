@@ -97,7 +97,9 @@ def test_run_time_compiled_kernels_against_oracle(oracle, tmp_path, monkeypatch)
     such kernels, the slice loop (one and two species, with and without the empty-slice short cut) meets the float64 oracle,
     the code object lands in the directory cache, and the run-time-length kernels (jit = 0) give the same physics."""
     monkeypatch.setenv("FDES_JIT_CACHE", str(tmp_path / "jit"))
-    for m, nz in ((1100, 1), (572, 2)):
+    import os
+    sizes = ((1100, 1), (572, 2)) if os.environ.get("FDES_GPU_SUITE") == "full" else ((572, 2),)   # (1100^2: tests/test_gpu_r3.py runs its slice loop on the run-time-length kernels)
+    for m, nz in sizes:
         hp, at = S.case_tiny(m=m, m3=5, nz=nz, nat=300, tilt=True, seed=51 + nz)
         fdes_amd.consistent(hp)
         q, _ = oracle.sub_sliced(hp)
@@ -121,7 +123,7 @@ def test_run_time_compiled_kernels_against_oracle(oracle, tmp_path, monkeypatch)
                 eng.close()
         assert relerr(waves[1], waves[0]) < 2e-6
     cached = sorted(p.name for p in (tmp_path / "jit").iterdir())
-    assert len(cached) == 2 and cached[0].startswith("gpass_1100_") and cached[1].startswith("gpass_572_"), cached
+    assert len(cached) == len(sizes) and cached[-1].startswith("gpass_572_"), cached
     assert all((tmp_path / "jit" / n).read_bytes()[:8] == b"FDESJIT1" and (tmp_path / "jit" / n).read_bytes()[24:28] == b"\x7fELF" for n in cached)
 
 
@@ -251,7 +253,7 @@ def test_run_time_compilation_cache_survives_a_damaged_file(tmp_path):
     assert files[0].stat().st_size > 10000               # dropped, compiled again, cached again
 
 
-@pytest.mark.parametrize("m1,m2", [(8192, 256), (256, 6144), (4800, 500), pytest.param(5000, 5000, marks=full_only)])
+@pytest.mark.parametrize("m1,m2", [(8192, 256), pytest.param(256, 6144, marks=full_only), (4800, 500), pytest.param(5000, 5000, marks=full_only)])
 def test_rows_beyond_4096_points(oracle, tmp_path, monkeypatch, m1, m2):
     """Grid lengths of 4098 ... 8192 points (even, 2^a 3^b 5^c 7^d 11^e 13^f; cufftPlan2d serves any size alike,
     src/paramStructure.cu:676-679) run the fused loop on kernels compiled at plan creation - one tile image of two rows, three
