@@ -293,3 +293,18 @@ def test_rows_beyond_4096_points(oracle, tmp_path, monkeypatch, m1, m2):
     assert pl.fft_backend() == 1 and pl.jit_kernels() == 0      # no kernels without the compilation: rocFFT, as every unsupported size
     pl.close()
     eng.close()
+
+
+def test_multi_gpu_driver_on_run_time_compiled_kernels(oracle, tmp_path, monkeypatch):
+    """fdes_build_measurements_multi with three host threads (all on GPU 0 here) on a grid length whose kernels are compiled at
+    plan creation: the workers meet in the compilation (one compiles, the others take its code object and load the module - the
+    per-device lock and the compilation lock are taken in that order everywhere), and the summed image equals the oracle's."""
+    monkeypatch.setenv("FDES_JIT_CACHE", str(tmp_path / "jit"))
+    monkeypatch.setenv("FDES_JIT", "1")
+    hp, at = S.case_tiny(m=616, m3=4, nz=2, frPh=5, nat=150, n3=2, tilt=True, seed=9)   # 616 = 8 * 7 * 11: a length no other test of this process compiles
+    fdes_amd.consistent(hp)
+    img = fdes_amd.build_measurements_multi([0, 0, 0], hp, at)
+    e = relerr(img, oracle.build_measurements(hp, at, prec="f32")["image"])
+    print(f"[parity] three workers, 616^2 on run-time-compiled kernels: E = {e:.3e}")
+    assert len(list((tmp_path / "jit").iterdir())) == 1   # compiled once for the three workers
+    assert e <= 1e-5
