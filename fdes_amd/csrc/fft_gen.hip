@@ -226,7 +226,10 @@ __host__ __device__ constexpr int gen_rows(int n)
     return n > 2048 ? (((FDES_GEN_ROWS4 || FDES_GEN_T1024) && gen_specialised(n)) ? 4 : 2) : (n > 512 ? 4 : 8);
 }
 constexpr int kGenThreads = 512; // threads of a workgroup (gen_threads below: 1024 for the four-row tiles of FDES_GEN_T1024)
-__host__ __device__ constexpr bool gen_t1024(int n) { return FDES_GEN_T1024 && n > 2048 && gen_specialised(n); }
+#ifndef FDES_GEN_BIG_T1024
+#define FDES_GEN_BIG_T1024 1 // rows beyond 4096 points (one two-row tile per CU): 1024 threads, i.e. sixteen waves instead of eight behind the same tile
+#endif
+__host__ __device__ constexpr bool gen_t1024(int n) { return (FDES_GEN_T1024 && n > 2048 && gen_specialised(n)) || (FDES_GEN_BIG_T1024 && n > 4096 && (n & (n - 1)) != 0); } // (measured, profiles/r05_rows_beyond_4096.txt: 4800^2 +33 %, 8000^2 +31 %, 6144^2 +11 %, 5000^2 +4 %; 8192^2 -16 %: it keeps 512 threads and 256 registers)
 __host__ __device__ constexpr int gen_threads(int n) { return gen_t1024(n) ? 1024 : kGenThreads; }
 __host__ __device__ constexpr int gen_lthreads(int n) { return gen_t1024(n) ? 10 : 9; }
 __host__ __device__ constexpr int gen_lrows(int rows) { return rows == 2 ? 1 : (rows == 4 ? 2 : 3); }
@@ -452,7 +455,7 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
 __host__ __device__ constexpr int gen_tw_mode(int n, int rows, bool one_image)
 {
     if (!one_image) return n <= 2048 ? 1 : 0;
-    const size_t limit = gen_t1024(n) ? (size_t)160 * 1024 : (size_t)FDES_GEN_TW_LDS_LIMIT; // (the four-row tiles are alone on their CU)
+    const size_t limit = (gen_t1024(n) || n > 4096) ? (size_t)160 * 1024 : (size_t)FDES_GEN_TW_LDS_LIMIT; // (the four-row tiles, and every tile of rows beyond 4096 points, are alone on their CU)
     if (sizeof(float) * 2 * ((size_t)rows * n + n) + 64 <= limit) return 1;
     if (n % 2 == 0 && sizeof(float) * 2 * ((size_t)rows * n + n / 2) + 64 <= limit) return 2;
     return 0;
@@ -1141,7 +1144,7 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
 }
 // waves per SIMD the register allocation is held to: EPT <= 8 (rows up to 1024 points) and the one-image kernels: two workgroups
 // per CU (the species loop of MID_GTABN needs more than 128 registers)
-#define FDES_GPASS_BOUNDS(NC, EPT, MID) __launch_bounds__(fdes::gen_threads(NC), ((((EPT) <= 8 || ((NC) != 0 && fdes::gen_one_image(NC))) && (MID) != fdes::MID_GTABN && (NC) <= 4096) ? 4 : 2)) // (rows beyond 4096 points: a tile of two rows is 80 ... 128 KiB, one workgroup per CU may use 256 registers)
+#define FDES_GPASS_BOUNDS(NC, EPT, MID) __launch_bounds__(fdes::gen_threads(NC), ((((EPT) <= 8 || ((NC) != 0 && fdes::gen_one_image(NC))) && (MID) != fdes::MID_GTABN && (NC) <= 4096) ? 4 : (fdes::gen_threads(NC) == 1024 ? 4 : 2))) // (rows beyond 4096 points: a tile of two rows is 80 ... 128 KiB, one workgroup per CU may use 256 registers)
 template <int NC, int EPT, int PRE, int MID, int POST, bool STORE_T>
 __global__ FDES_GPASS_BOUNDS(NC, EPT, MID) void k_gpass(PassArgs A, GenFac Frt)
 {
@@ -1312,6 +1315,7 @@ int gen_pass_tile_rows(int n, int nrows)
     return 0;
 }
 bool gen_pass_compiled_in(int n) { return FDES_GEN_SPECIALISED && gen_specialised(n); }
+int gen_pass_threads(int n) { return gen_threads(n); }
 
 void gen_pass_twiddles(int n, float* tw)
 {

@@ -107,7 +107,7 @@ std::map<std::pair<int, int>, std::string> g_from_file;         // (length, tile
 std::map<std::pair<int, int>, std::string> g_failed;            // (length, tile rows) -> why it has no code object (not tried again)
 std::map<std::pair<std::pair<int, int>, int>, GenJitKernels*> g_mod; // ((length, tile rows), device) -> loaded module
 
-int ept_of(int n, int rows) { const int e = (rows * n + 511) / 512; return e <= 8 ? 8 : (e <= 16 ? 16 : 32); }
+int ept_of(int n, int rows) { const int t = gen_pass_threads(n), e = (rows * n + t - 1) / t; return e <= 8 ? 8 : (e <= 16 ? 16 : 32); }
 
 // code object of the n-point passes: from this process, from the directory cache, or compiled now
 const std::vector<char>* code_for(int n, int rows, std::string* note)
@@ -222,7 +222,7 @@ const GenJitKernels* gen_jit_prepare(int n, int rows, std::string* note)
     k->n = n;
     k->rows = rows;
     k->device = dev;
-    k->threads = 512;
+    k->threads = gen_pass_threads(n);
     hipModule_t mod = nullptr;
     hipError_t le = hipModuleLoadData(&mod, code->data());
     if (le != hipSuccess) {

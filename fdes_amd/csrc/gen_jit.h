@@ -29,6 +29,8 @@ void* gen_jit_function(const GenJitKernels* k, int pre, int mid, int post, bool 
 
 // fft_gen.hip: lengths whose compile-time kernels are part of the library
 bool gen_pass_compiled_in(int n);
+// threads of a workgroup of the compile-time kernels of this length (512; 1024 beyond 4096 points)
+int gen_pass_threads(int n);
 
 } // namespace fdes
 #endif
