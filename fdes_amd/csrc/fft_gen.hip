@@ -120,7 +120,7 @@ __host__ __device__ constexpr bool gen_auto_three_stages(int n, int (&r)[3])
     return best >= 0;
 }
 
-// the same with FOUR stages for the lengths three cannot serve (8192 = 16 x 16 x 8 x 4, 6144, 7168 ...: rows beyond 4096 points,
+// the same with FOUR stages for the lengths three cannot serve (8192 = 2 x 16 x 16 x 16, 6144 = 8 x 12 x 8 x 8, 7168 = 7 x 16 x 16 x 4 ...: rows beyond 4096 points,
 // run-time compilation only): smallest largest radix, odd first radix where one exists, then the larger second radix
 __host__ __device__ constexpr bool gen_auto_four_stages(int n, int (&r)[4])
 {
@@ -169,7 +169,7 @@ __host__ __device__ constexpr bool factorize(int n, GenFac& f)
     }
 #endif
     // large radices first: fewer stages (each stage is one trip of the tile through LDS)
-    const int cand[9] = {13, 11, 10, 8, 7, 5, 4, 3, 2}; // (round 5, second half: 11 and 13, run-time-length kernels only)
+    const int cand[9] = {13, 11, 10, 8, 7, 5, 4, 3, 2}; // (round 5, second half: 11 and 13)
     for (int ci = 0; ci < 9; ci++)
         while (m % cand[ci] == 0 && m > 1) {
             if (f.nf == 8) return false;

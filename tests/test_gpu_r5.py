@@ -257,7 +257,7 @@ def test_run_time_compilation_cache_survives_a_damaged_file(tmp_path):
 def test_rows_beyond_4096_points(oracle, tmp_path, monkeypatch, m1, m2):
     """Grid lengths of 4098 ... 8192 points (even, 2^a 3^b 5^c 7^d 11^e 13^f; cufftPlan2d serves any size alike,
     src/paramStructure.cu:676-679) run the fused loop on kernels compiled at plan creation - one tile image of two rows, three
-    or four stages (8192 = 16 x 16 x 8 x 4) - instead of the rocFFT + point-wise loop; with jit = 0 they take rocFFT as before.
+    or four stages (8192 = 2 x 16 x 16 x 16) - instead of the rocFFT + point-wise loop; with jit = 0 they take rocFFT as before.
     Rectangular grids keep the oracle cheap: 2-D FFT against numpy, slice loop and potential against the float64 oracle."""
     monkeypatch.setenv("FDES_JIT_CACHE", str(tmp_path / "jit"))
     rng = np.random.default_rng(11)
