@@ -120,11 +120,24 @@ __host__ __device__ constexpr bool gen_auto_three_stages(int n, int (&r)[3])
     return best >= 0;
 }
 
-// the same with FOUR stages for the lengths three cannot serve (8192 = 2 x 16 x 16 x 16, 6144 = 8 x 12 x 8 x 8, 7168 = 7 x 16 x 16 x 4 ...: rows beyond 4096 points,
+// the same with FOUR stages for the lengths three cannot serve (8192 = 8 x 16 x 16 x 4, 6144 = 12 x 16 x 8 x 4, 7168 = 7 x 16 x 16 x 4 ...: rows beyond 4096 points,
 // run-time compilation only): smallest largest radix, odd first radix where one exists, then the larger second radix
 __host__ __device__ constexpr bool gen_auto_four_stages(int n, int (&r)[4])
 {
     const int S[14] = {25, 20, 16, 15, 13, 12, 11, 10, 8, 7, 5, 4, 3, 2};
+    if (n % 64 == 0) { // measured (profiles/r05_rows_beyond_4096.txt): a x 16 x c x 4 with a medium first radix - 8192 = 8 x 16 x 16 x 4 (+24 % over 2 x 16 x 16 x 16),
+                       // 6144 = 12 x 16 x 8 x 4 (+11 % over 8 x 12 x 8 x 8), 7680 = 12 x 16 x 10 x 4 (+22 %), 7168 = 7 x 16 x 16 x 4; a first radix of 16 loses 5 ... 20 %
+        const int pref[14] = {12, 10, 8, 15, 7, 5, 13, 11, 3, 20, 25, 16, 4, 2};
+        const int rest = n / 64;
+        for (int ia = 0; ia < 14; ia++) {
+            const int a = pref[ia];
+            if (rest % a != 0) continue;
+            const int c = rest / a;
+            bool ok = false;
+            for (int ic = 0; ic < 14; ic++) ok = ok || S[ic] == c;
+            if (ok) { r[0] = a; r[1] = 16; r[2] = c; r[3] = 4; return true; }
+        }
+    }
     long best = -1;
     for (int ia = 0; ia < 14; ia++)
         for (int ib = 0; ib < 14; ib++)
@@ -181,6 +194,13 @@ __host__ __device__ constexpr bool factorize(int n, GenFac& f)
     {   // run-time compilation of ONE length (gen_jit.cpp): three stages with composite radices where the single radices need more,
         // chosen as the hand-measured table above suggests (gen_auto_three_stages)
         int cr[3] = {0, 0, 0}, c4[4] = {0, 0, 0, 0};
+#ifdef FDES_GEN_JIT_R0 // tuning knob (FDES_JIT_STAGES=a,b,c[,d] -> gen_jit.cpp): the stage radices of this compilation, given outright
+        if (n == FDES_GEN_JIT_N && (long)FDES_GEN_JIT_R0 * FDES_GEN_JIT_R1 * FDES_GEN_JIT_R2 * FDES_GEN_JIT_R3 == n) {
+            c4[0] = FDES_GEN_JIT_R0; c4[1] = FDES_GEN_JIT_R1; c4[2] = FDES_GEN_JIT_R2; c4[3] = FDES_GEN_JIT_R3;
+            f.nf = FDES_GEN_JIT_R3 > 1 ? 4 : 3;
+            for (int q = 0; q < 8; q++) f.radix[q] = q < f.nf ? c4[q] : 0;
+        } else
+#endif
         if (n == FDES_GEN_JIT_N && n > 512 && f.nf > 3 && gen_auto_three_stages(n, cr)) {
             f.nf = 3;
             for (int q = 0; q < 8; q++) f.radix[q] = q < 3 ? cr[q] : 0;

@@ -126,8 +126,25 @@ const std::vector<char>* code_for(int n, int rows, std::string* note)
     if (!R.ok) return fail("libhiprtc not found");
     const std::string o_n = "-DFDES_GEN_JIT_N=" + std::to_string(n), o_e = "-DFDES_GEN_JIT_EPT=" + std::to_string(ept_of(n, rows)),
                       o_r = "-DFDES_GEN_JIT_ROWS=" + std::to_string(rows);
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DFDES_TEST_HOOKS=0", o_n.c_str(), o_e.c_str(), o_r.c_str()};
-    const int nopts = (int)(sizeof(opts) / sizeof(opts[0])) - (rows == gen_pass_rows(n) ? 1 : 0); // (the length's own tile rows: no option, and the cache entries of earlier builds stay valid)
+    // tuning knob: FDES_JIT_STAGES=a,b,c[,d] gives the stage radices of every compilation of this process outright (product = the length,
+    // radices out of 2 ... 5, 7, 8, 10 ... 13, 15, 16, 20, 25; anything else is ignored); part of the cache key like every option
+    std::string o_s[4];
+    int nstage_opts = 0;
+    if (const char* e = std::getenv("FDES_JIT_STAGES")) {
+        int r[4] = {0, 0, 0, 1};
+        const int got = std::sscanf(e, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]);
+        auto okr = [](int v) { for (int c : {2, 3, 4, 5, 7, 8, 10, 11, 12, 13, 15, 16, 20, 25}) if (v == c) return true; return false; };
+        if (got >= 3 && okr(r[0]) && okr(r[1]) && okr(r[2]) && (got == 3 || okr(r[3])) && (long)r[0] * r[1] * r[2] * (got == 3 ? 1 : r[3]) == n) {
+            if (got == 3) r[3] = 1;
+            for (int q = 0; q < 4; q++) o_s[q] = "-DFDES_GEN_JIT_R" + std::to_string(q) + "=" + std::to_string(r[q]);
+            nstage_opts = 4;
+        }
+    }
+    const bool own_rows = rows == gen_pass_rows(n); // (the length's own tile rows: no option, and the cache entries of earlier builds stay valid)
+    const char* opts[12] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DFDES_TEST_HOOKS=0", o_n.c_str(), o_e.c_str()};
+    int nopts = 7;
+    if (!own_rows) opts[nopts++] = o_r.c_str();
+    for (int q = 0; q < nstage_opts; q++) opts[nopts++] = o_s[q].c_str();
     int vmaj = 0, vmin = 0;
     if (R.Version) (void)R.Version(&vmaj, &vmin);
     unsigned long long h = 1469598103934665603ull;
