@@ -93,8 +93,9 @@ __host__ __device__ constexpr bool gen_three_stages(int n, int (&r)[3])
 
 // n = a b c with radices the compile-time kernels have butterflies for, for a length outside the table above: the most balanced
 // triple (smallest largest radix: fewest registers per butterfly); first radix odd where one exists (conflict-free first-stage
-// writes), else 10, 12, 8, 16, 20, 4, 2 in this order; then the larger middle radix - the choices the measured table makes for
-// 1280 ... 4000 (3200 excepted: 10 x 16 x 20 there, within a few per cent)
+// writes; not 25), else 10, 12, 8, 16, 20, 4, 2 in this order; then a last radix other than 16, then the larger middle radix - the choices
+// the measured table makes for 1280 ... 4000 (3200 excepted: 10 x 16 x 20 there, within a few per cent), checked beyond 4096 points
+// (profiles/r05_rows_beyond_4096.txt: 5000, 4800, 8000, 3840)
 __host__ __device__ constexpr bool gen_auto_three_stages(int n, int (&r)[3])
 {
     const int S[14] = {25, 20, 16, 15, 13, 12, 11, 10, 8, 7, 5, 4, 3, 2};
@@ -110,11 +111,12 @@ __host__ __device__ constexpr bool gen_auto_three_stages(int n, int (&r)[3])
             if (!ok) continue;
             const int mx = a > b ? (a > c ? a : c) : (b > c ? b : c);
             int apref = 0; // larger is better
-            if (a % 2 == 1) apref = 100 + a;
+            if (a % 2 == 1 && a <= 15) apref = 100 + a; // (25 as the first radix: 5000 = 25 x 25 x 8 ran 15 % behind 10 x 25 x 20)
             else
                 for (int e = 0; e < 7; e++)
                     if (evenpref[e] == a) apref = 50 - e;
-            const long score = (long)(64 - mx) * 1000000 + (long)apref * 1000 + b;
+            // (a last radix of 16 keeps the trailing transform of a chained pass from starting in registers: 4800 = 15 x 16 x 20 ran 9 % ahead of 15 x 20 x 16)
+            const long score = (long)(64 - mx) * 1000000 + (long)apref * 1000 + (c != 16 ? 500 : 0) + b;
             if (score > best) { best = score; r[0] = a; r[1] = b; r[2] = c; }
         }
     return best >= 0;
