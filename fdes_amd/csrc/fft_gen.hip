@@ -252,8 +252,14 @@ constexpr int kGenThreads = 512; // threads of a workgroup (gen_threads below: 1
 #define FDES_GEN_BIG_T1024 1 // rows beyond 4096 points (one two-row tile per CU): 1024 threads, i.e. sixteen waves instead of eight behind the same tile
 #endif
 __host__ __device__ constexpr bool gen_t1024(int n) { return (FDES_GEN_T1024 && n > 2048 && gen_specialised(n)) || (FDES_GEN_BIG_T1024 && n > 4096 && (n & (n - 1)) != 0); } // (measured, profiles/r05_rows_beyond_4096.txt: 4800^2 +33 %, 8000^2 +31 %, 6144^2 +11 %, 5000^2 +4 %; 8192^2 -16 %: it keeps 512 threads and 256 registers)
-__host__ __device__ constexpr int gen_threads(int n) { return gen_t1024(n) ? 1024 : kGenThreads; }
-__host__ __device__ constexpr int gen_lthreads(int n) { return gen_t1024(n) ? 10 : 9; }
+__host__ __device__ constexpr int gen_threads(int n)
+{
+#ifdef FDES_GEN_JIT_THREADS // run-time compilation: 256 threads for small tiles (gen_pass_threads_for)
+    if (n == FDES_GEN_JIT_N) return FDES_GEN_JIT_THREADS;
+#endif
+    return gen_t1024(n) ? 1024 : kGenThreads;
+}
+__host__ __device__ constexpr int gen_lthreads(int n) { return gen_threads(n) == 1024 ? 10 : (gen_threads(n) == 256 ? 8 : 9); }
 __host__ __device__ constexpr int gen_lrows(int rows) { return rows == 2 ? 1 : (rows == 4 ? 2 : 3); }
 // rows beyond 2048 points: the tile images fill the LDS, the twiddle table is read from global memory
 __host__ __device__ constexpr bool gen_tw_in_lds(int n) { return n <= 2048; }
@@ -1338,6 +1344,14 @@ int gen_pass_tile_rows(int n, int nrows)
 }
 bool gen_pass_compiled_in(int n) { return FDES_GEN_SPECIALISED && gen_specialised(n); }
 int gen_pass_threads(int n) { return gen_threads(n); }
+// threads of a workgroup of kernels compiled at plan creation for (length, tile rows): two-row tiles of short rows keep 50 ... 250 of the
+// 256 threads of a row busy and leave four rows per CU in flight: 256-thread workgroups (four per CU) up to 1280 points - measured
+// (profiles/r05_smaller_tiles.txt): 750^2 +13 %, 1250^2 +24 %, 1430^2 +-0, 2002^2 -15 %
+int gen_pass_threads_for(int n, int rows)
+{
+    if (const char* e = std::getenv("FDES_GEN_SMALL_TILE_THREADS")) { if (std::atoi(e) == 512) return gen_threads(n); } // (measurement knob)
+    return (rows == 2 && n <= 1280) ? 256 : gen_threads(n);
+}
 
 void gen_pass_twiddles(int n, float* tw)
 {

@@ -107,7 +107,7 @@ std::map<std::pair<int, int>, std::string> g_from_file;         // (length, tile
 std::map<std::pair<int, int>, std::string> g_failed;            // (length, tile rows) -> why it has no code object (not tried again)
 std::map<std::pair<std::pair<int, int>, int>, GenJitKernels*> g_mod; // ((length, tile rows), device) -> loaded module
 
-int ept_of(int n, int rows) { const int t = gen_pass_threads(n), e = (rows * n + t - 1) / t; return e <= 8 ? 8 : (e <= 16 ? 16 : 32); }
+int ept_of(int n, int rows) { const int t = gen_pass_threads_for(n, rows), e = (rows * n + t - 1) / t; return e <= 8 ? 8 : (e <= 16 ? 16 : 32); }
 
 // code object of the n-point passes: from this process, from the directory cache, or compiled now
 const std::vector<char>* code_for(int n, int rows, std::string* note)
@@ -141,9 +141,11 @@ const std::vector<char>* code_for(int n, int rows, std::string* note)
         }
     }
     const bool own_rows = rows == gen_pass_rows(n); // (the length's own tile rows: no option, and the cache entries of earlier builds stay valid)
-    const char* opts[12] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DFDES_TEST_HOOKS=0", o_n.c_str(), o_e.c_str()};
+    const char* opts[16] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DFDES_TEST_HOOKS=0", o_n.c_str(), o_e.c_str()};
     int nopts = 7;
     if (!own_rows) opts[nopts++] = o_r.c_str();
+    const std::string o_t = "-DFDES_GEN_JIT_THREADS=" + std::to_string(gen_pass_threads_for(n, rows));
+    if (gen_pass_threads_for(n, rows) != gen_pass_threads(n)) opts[nopts++] = o_t.c_str();
     for (int q = 0; q < nstage_opts; q++) opts[nopts++] = o_s[q].c_str();
     int vmaj = 0, vmin = 0;
     if (R.Version) (void)R.Version(&vmaj, &vmin);
@@ -239,7 +241,7 @@ const GenJitKernels* gen_jit_prepare(int n, int rows, std::string* note)
     k->n = n;
     k->rows = rows;
     k->device = dev;
-    k->threads = gen_pass_threads(n);
+    k->threads = gen_pass_threads_for(n, rows);
     hipModule_t mod = nullptr;
     hipError_t le = hipModuleLoadData(&mod, code->data());
     if (le != hipSuccess) {

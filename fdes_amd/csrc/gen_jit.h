@@ -31,6 +31,7 @@ void* gen_jit_function(const GenJitKernels* k, int pre, int mid, int post, bool 
 bool gen_pass_compiled_in(int n);
 // threads of a workgroup of the compile-time kernels of this length (512; 1024 beyond 4096 points)
 int gen_pass_threads(int n);
+int gen_pass_threads_for(int n, int rows); // ... of the kernels compiled at plan creation for these tile rows
 
 } // namespace fdes
 #endif
