@@ -141,12 +141,27 @@ const std::vector<char>* code_for(int n, int rows, std::string* note)
         }
     }
     const bool own_rows = rows == gen_pass_rows(n); // (the length's own tile rows: no option, and the cache entries of earlier builds stay valid)
-    const char* opts[16] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DFDES_TEST_HOOKS=0", o_n.c_str(), o_e.c_str()};
+    const char* opts[20] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DFDES_TEST_HOOKS=0", o_n.c_str(), o_e.c_str()};
     int nopts = 7;
     if (!own_rows) opts[nopts++] = o_r.c_str();
     const std::string o_t = "-DFDES_GEN_JIT_THREADS=" + std::to_string(gen_pass_threads_for(n, rows));
     if (gen_pass_threads_for(n, rows) != gen_pass_threads(n)) opts[nopts++] = o_t.c_str();
     for (int q = 0; q < nstage_opts; q++) opts[nopts++] = o_s[q].c_str();
+    // tuning knob: FDES_JIT_FLAGS = up to four more compiler options, space separated (e.g. "-mllvm -amdgpu-sched-strategy=max-ilp")
+    std::string o_x[4];
+    if (const char* e = std::getenv("FDES_JIT_FLAGS")) {
+        std::string all(e);
+        size_t pos = 0;
+        int nx = 0;
+        while (nx < 4 && pos < all.size()) {
+            const size_t sp = all.find(' ', pos);
+            const std::string tok = all.substr(pos, sp == std::string::npos ? std::string::npos : sp - pos);
+            if (!tok.empty()) o_x[nx++] = tok;
+            if (sp == std::string::npos) break;
+            pos = sp + 1;
+        }
+        for (int q = 0; q < nx; q++) opts[nopts++] = o_x[q].c_str();
+    }
     int vmaj = 0, vmin = 0;
     if (R.Version) (void)R.Version(&vmaj, &vmin);
     unsigned long long h = 1469598103934665603ull;
