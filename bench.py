@@ -511,7 +511,8 @@ def run_extras(device):
     # fused mixed-radix passes with compiled-in kernels; until round 3: rocFFT + point-wise kernels); nx = 1144 -> 2288 = 16 x 11 x 13
     # points (round 5: no compiled-in kernels - the row passes are compiled for the length by hipRTC when the plan is created,
     # gen_jit.cpp; `plan_creation_s` holds that compilation, or the read from the directory cache).  C3 specimen, 32 slices,
-    # 2 untimed + 6 timed configurations, every slice the full sequence
+    # 2 untimed + 6 timed configurations, every slice the full sequence.  nx = 2500 -> 5000 points: rows beyond 4096 points exist on the
+    # fused loop as run-time-compiled kernels only (round 5)
     def grid_extra(nx):
         hp, at = specimens.case_c3(k=30, n=nx, dn=nx // 2, m3=32, frPh=32)
         fdes_amd.consistent(hp)
@@ -549,6 +550,7 @@ def run_extras(device):
         return r
     out["qsc_sized_grid"] = grid_extra(1500)
     out["run_time_compiled_grid"] = grid_extra(1144)
+    out["grid_beyond_4096"] = grid_extra(2500)   # 5000 = 10 x 25 x 20 points: one two-row tile per CU, kernels compiled at plan creation (rocFFT loop before: 0.20 k)
     # BASELINE config 4 at full size: SrTiO3 beam-tilt series, 64 tilts x 8 frozen-phonon configurations, 1024^2 wave, 40
     # slices, every slice the full sequence; engine defaults (lanes of gangs); one untimed job, one timed job
     hp, at = specimens.case_c4()
