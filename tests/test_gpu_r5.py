@@ -313,3 +313,37 @@ def test_multi_gpu_driver_on_run_time_compiled_kernels(oracle, tmp_path, monkeyp
     print(f"[parity] three workers, 616^2 on run-time-compiled kernels: E = {e:.3e}")
     assert len(list((tmp_path / "jit").iterdir())) == 1   # compiled once for the three workers
     assert e <= 1e-5
+
+
+_JIT_STAGES_PROBE = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import fdes_amd
+from tests import specimens as S, oracle_py
+from tests.test_gpu_parity import relerr
+oracle_py.lib()
+hp, at = S.case_tiny(m=1100, m3=3, nz=2, nat=200, tilt=True, seed=4)
+fdes_amd.consistent(hp)
+q, _ = oracle_py.sub_sliced(hp)
+ref = oracle_py.wave(q, at, 0, 0, prec="f64")
+eng = fdes_amd.Engine(0, jit=1, skip_empty=0)
+pl = eng.plan(hp, at)
+print("axes", pl.jit_kernels(), "E", relerr(pl.tap_wave(0, 0), ref))
+pl.close(); eng.close()
+'''
+
+
+@pytest.mark.parametrize("stages", ["10,10,11", "5,20,11", "11,4,5,5"])
+def test_run_time_compilation_with_given_stage_orders(tmp_path, stages):
+    """FDES_JIT_STAGES (a tuning knob) gives the stage radices of a compilation outright: any order of supported radices whose
+    product is the length - three or four stages, prime and composite radices anywhere - must give the same physics (1100^2 slice
+    loop against the float64 oracle, in a process of its own: the knob is read when a length is first compiled)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FDES_JIT_CACHE=str(tmp_path / "jit"), FDES_JIT="1", FDES_JIT_STAGES=stages)
+    r = subprocess.run([sys.executable, "-c", _JIT_STAGES_PROBE, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "axes 2" in r.stdout, r.stdout + r.stderr
+    e = float(r.stdout.split("E")[-1])
+    print(f"[parity] 1100^2 slice loop with stages {stages}: E = {e:.3e}")
+    assert e <= 1e-5
