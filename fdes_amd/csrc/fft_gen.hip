@@ -850,6 +850,10 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
         if (bg >= g_lo) bg = g_hi + (bg - g_lo);
     }
     const int row0 = bg * R;
+    // The LAST tile of a grid whose row count R does not divide is partial (round 5: 750^2, odd lengths): rows row0 + rvalid ... are not
+    // there.  Their threads run along (every barrier is the workgroup's), read the tile's last valid row instead of memory behind the
+    // grid (erl / rowl below: a load address only), and nothing of theirs is stored.
+    const int rvalid = (A.nrows - row0 < R) ? A.nrows - row0 : R;
     const unsigned pin = A.pitch_in ? (unsigned)A.pitch_in : (unsigned)N;
     const unsigned ldt = A.pitch_out ? (unsigned)A.pitch_out : (unsigned)A.nrows;
     const size_t gbase = (size_t)row0 * pin;
@@ -882,13 +886,14 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
             ec[i] = c + i * tpr;
         }
     }
+    const int erl = (er[0] < rvalid) ? er[0] : rvalid - 1; // this thread's row as a LOAD address (every element of a thread lies in one row)
     auto valid = [&](int i) { return ec[i] < N; };
     auto load_tile = [&](const cf* __restrict__ src, cf* __restrict__ dstl, const bool band) {
 #pragma unroll
         for (int i = 0; i < EPT; i++)
             if (valid(i)) {
                 const bool dead = band && dead_index(iwc(ec[i], N), A.band);
-                dstl[er[i] * N + ec[i]] = dead ? cf{0.f, 0.f} : src[(unsigned)er[i] * pin + (unsigned)ec[i]];
+                dstl[er[i] * N + ec[i]] = dead ? cf{0.f, 0.f} : src[(unsigned)erl * pin + (unsigned)ec[i]];
             }
     };
 
@@ -901,6 +906,7 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
         using SL = GStage<NN, QL>;
         const int row = tid >> (LTHR - FC.lrows), jt = tid & (SL::tpr - 1);
         const int grow = row0 + row;
+        const int rowl = (row < rvalid) ? row : rvalid - 1, growl = row0 + rowl; // (load addresses of a partial tile's missing rows)
         const float sp = (PRE == XF_INV) ? -1.f : 1.f, sq = (POST == XF_INV) ? -1.f : 1.f;
         cf* __restrict__ rowp = cur + row * NN;
         cf xa[SL::NBT][SL::RX];
@@ -911,10 +917,10 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
             // transformed), the twiddle table moves into LDS behind the requests (the first stage needs no twiddle)
             XArr<NN, 0> x0, xpre;
             if constexpr (MID == MID_MULPSI) {
-                gs_load_global<NN, 0>(x0, in1 + (unsigned)row * pin, jt, (A.skip_dead_loads & 2) != 0, A.band);
-                if constexpr (FDES_GEN_PREFETCH_B) gs_load_global<NN, 0>(xpre, in0 + (unsigned)row * pin, jt, (A.skip_dead_loads & 1) != 0, A.band);
+                gs_load_global<NN, 0>(x0, in1 + (unsigned)rowl * pin, jt, (A.skip_dead_loads & 2) != 0, A.band);
+                if constexpr (FDES_GEN_PREFETCH_B) gs_load_global<NN, 0>(xpre, in0 + (unsigned)rowl * pin, jt, (A.skip_dead_loads & 1) != 0, A.band);
             } else {
-                gs_load_global<NN, 0>(x0, in0 + (unsigned)row * pin, jt, (A.skip_dead_loads & 1) != 0, A.band);
+                gs_load_global<NN, 0>(x0, in0 + (unsigned)rowl * pin, jt, (A.skip_dead_loads & 1) != 0, A.band);
             }
             if (tw_lds) {
                 const cf* __restrict__ tw = reinterpret_cast<const cf*>(A.tw0);
@@ -924,7 +930,7 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
             if constexpr (MID == MID_MULPSI) {
                 gen_chain_to_regs<NN, 0, true, true>(cur, nullptr, false, 0, twl, sp, row, jt, xb, x0);
                 if constexpr (FDES_GEN_PREFETCH_B) gen_chain_to_regs<NN, 0, true, true>(cur, nullptr, false, 0, twl, sp, row, jt, xa, xpre);
-                else gen_chain_to_regs<NN, 0, true>(cur, in0 + (unsigned)row * pin, (A.skip_dead_loads & 1) != 0, A.band, twl, sp, row, jt, xa, x0);
+                else gen_chain_to_regs<NN, 0, true>(cur, in0 + (unsigned)rowl * pin, (A.skip_dead_loads & 1) != 0, A.band, twl, sp, row, jt, xa, x0);
             } else {
                 gen_chain_to_regs<NN, 0, true, true>(cur, nullptr, false, 0, twl, sp, row, jt, xa, x0);
             }
@@ -939,10 +945,10 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
                     const int p = rdx_slot<SL::RX>(i);
                     const int col = j + i * SL::Ns; // last stage: k = j
                     cf v = xa[b][p];
-                    if constexpr (MID == MID_GTAB) v = v * gtab[(unsigned)row * pin + (unsigned)col];
+                    if constexpr (MID == MID_GTAB) v = v * gtab[(unsigned)rowl * pin + (unsigned)col];
                     if constexpr (MID == MID_MASK) v = gen_outside(iwc(col, NN), iwc(grow, A.nrows), md) ? cf{0.f, 0.f} : v * A.scale;
                     if constexpr (MID == MID_PTAB) {
-                        const cf pr = reinterpret_cast<const cf*>(A.prow)[grow], pc = reinterpret_cast<const cf*>(A.pcol)[col];
+                        const cf pr = reinterpret_cast<const cf*>(A.prow)[growl], pc = reinterpret_cast<const cf*>(A.pcol)[col];
                         v = gen_outside(iwc(col, NN), iwc(grow, A.nrows), md) ? cf{0.f, 0.f} : cmul3(v, cmul3(pr, pc));
                     }
                     if constexpr (MID == MID_MULPSI) v = cmul3(v, xb[b][p]); // f0 = t, f1 = psi
@@ -962,6 +968,7 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
             cf* __restrict__ dst = outp + row0;
             for (int e = tid; e < tile; e += THR) {
                 const int c = e >> F.lrows, rr = e & (R - 1);
+                if (rr >= rvalid) continue; // (partial last tile)
                 if (A.skip_dead_stores && dead_index(iwc(c, N), A.band)) continue;
                 dst[(unsigned)c * ldt + (unsigned)rr] = cur[rr * N + c];
             }
@@ -1018,7 +1025,7 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
 #pragma unroll
             for (int i = 0; i < EPT; i++)
                 if (valid(i)) {
-                    const float gv = gtab[zo + (unsigned)er[i] * pin + (unsigned)ec[i]];
+                    const float gv = gtab[zo + (unsigned)erl * pin + (unsigned)ec[i]];
                     const cf v = cur[er[i] * N + ec[i]];
                     acc[i].x += v.x * gv;
                     acc[i].y += v.y * gv;
@@ -1049,7 +1056,8 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
             }
             if (phi[0] - plo[0] + phi[1] - plo[1] == 0) { // workgroup-uniform: the spectrum of an empty row group is zero
                 if constexpr (STORE_T) {
-                    for (int e = tid; e < tile; e += THR) (out0 + row0)[(unsigned)(e >> F.lrows) * ldt + (unsigned)(e & (R - 1))] = cf{0.f, 0.f};
+                    for (int e = tid; e < tile; e += THR)
+                        if ((e & (R - 1)) < rvalid) (out0 + row0)[(unsigned)(e >> F.lrows) * ldt + (unsigned)(e & (R - 1))] = cf{0.f, 0.f};
                 }
                 return;
             }
@@ -1092,7 +1100,7 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
             for (int i = 0; i < EPT; i++)
                 if (valid(i)) {
                     const bool dead = band0 && dead_index(iwc(ec[i], N), A.band);
-                    areg[i] = dead ? cf{0.f, 0.f} : in0[(unsigned)er[i] * pin + (unsigned)ec[i]];
+                    areg[i] = dead ? cf{0.f, 0.f} : in0[(unsigned)erl * pin + (unsigned)ec[i]];
                 }
             load_tile(in1, cur, (A.skip_dead_loads & 2) != 0);
             __syncthreads();
@@ -1115,10 +1123,10 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
                 cf v = cur[er[i] * N + ec[i]];
                 const int grow = row0 + er[i];
                 if constexpr (MID == MID_SCALE) v = v * A.scale;
-                if constexpr (MID == MID_GTAB) v = v * gtab[(unsigned)er[i] * pin + (unsigned)ec[i]];
+                if constexpr (MID == MID_GTAB) v = v * gtab[(unsigned)erl * pin + (unsigned)ec[i]];
                 if constexpr (MID == MID_MASK) v = gen_outside(iwc(ec[i], N), iwc(grow, A.nrows), md) ? cf{0.f, 0.f} : v * A.scale;
                 if constexpr (MID == MID_PTAB) {
-                    const cf pr = reinterpret_cast<const cf*>(A.prow)[grow], pc = reinterpret_cast<const cf*>(A.pcol)[ec[i]];
+                    const cf pr = reinterpret_cast<const cf*>(A.prow)[row0 + erl], pc = reinterpret_cast<const cf*>(A.pcol)[ec[i]];
                     v = gen_outside(iwc(ec[i], N), iwc(grow, A.nrows), md) ? cf{0.f, 0.f} : cmul3(v, cmul3(pr, pc));
                 }
                 if constexpr (MID == MID_MULPSI) v = cmul3(v, keep_b[i]); // f0 = t, f1 = psi
@@ -1140,12 +1148,13 @@ __device__ __forceinline__ void gpass_body(const PassArgs& A, const GenFac& Frt)
             cf* __restrict__ on = outp + (size_t)row0 * pout;
 #pragma unroll
             for (int i = 0; i < EPT; i++)
-                if (valid(i)) on[(unsigned)er[i] * pout + (unsigned)ec[i]] = cur[er[i] * N + ec[i]];
+                if (valid(i) && er[i] < rvalid) on[(unsigned)er[i] * pout + (unsigned)ec[i]] = cur[er[i] * N + ec[i]];
         } else {
             // transposed grid: N rows of length ldt; consecutive threads write the R consecutive elements of one output row
             cf* __restrict__ dst = outp + row0;
             for (int e = tid; e < tile; e += THR) {
                 const int c = e >> F.lrows, rr = e & (R - 1);
+                if (rr >= rvalid) continue; // (partial last tile)
                 if (A.skip_dead_stores && dead_index(iwc(c, N), A.band)) continue;
                 dst[(unsigned)c * ldt + (unsigned)rr] = cur[rr * N + c];
             }
@@ -1223,14 +1232,14 @@ inline hipError_t gen_launch_geometry(const PassArgs& a, const GenFac& f, bool c
     const int tw_mode = ct ? gen_tw_mode(f.n, f.rows, one) : (gen_tw_in_lds(f.n) ? 1 : 0);
     L.lds_bytes = sizeof(float) * 2 * ((size_t)f.rows * f.n * (one ? 1 : 2) + (tw_mode == 1 ? (size_t)f.n : (tw_mode == 2 ? (size_t)f.n / 2 : (size_t)0))) + 64;
     if (L.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    if (a.nrows % f.rows != 0) return hipErrorInvalidValue;
-    int groups = a.nrows / f.rows;
+    const int all_groups = (a.nrows + f.rows - 1) / f.rows; // (the last tile may be partial)
+    int groups = all_groups;
     L.w = a;
     if (a.live_rows_only) {
         if (a.band <= 0) return hipErrorInvalidValue;
         const int L_ = a.band_L;
         const int g_lo = L_ / f.rows + 1, g_hi = (a.nrows - L_) / f.rows;
-        if (g_hi > g_lo) groups = g_lo + (a.nrows / f.rows - g_hi);
+        if (g_hi > g_lo) groups = g_lo + (all_groups - g_hi);
         else L.w.live_rows_only = 0;
     }
     const int ny = (mid == MID_ATOMS) ? (a.nspecies > 0 ? a.nspecies : 1) : 1;
@@ -1330,17 +1339,23 @@ bool gen_pass_supported_len(int n)
 int gen_pass_rows(int n) { return gen_rows(n); }
 // Rows per tile for n-point rows of a grid with `nrows` of them: the length's own number (8 up to 512 points, 4 up to 2048, 2
 // beyond) or, where that does not divide nrows, the next smaller power of two that does - 500^2 runs four-row tiles, 750^2 (m = 2 nx
-// of a .qsc with an odd nx) two-row tiles instead of leaving the fused loop; 0: nrows is odd
+// of a .qsc with an odd nx) two-row tiles; where none does (an ODD nrows: 375^2, 1001^2) the length's own number with a PARTIAL last
+// tile (k_gpass: rvalid).  Measured (profiles/r05_smaller_tiles.txt): exact smaller tiles run level with or ahead of partial larger
+// ones (500^2 73.7 against 65.3 k, 2002^2 9.4 against 8.3 k), so the partial tile is the last resort.  FDES_GEN_PARTIAL_TILES = 1
+// (measurement knob): always the length's own rows with a partial last tile; = 0: never a partial tile (odd nrows: rocFFT).
 int gen_pass_tile_rows(int n, int nrows)
 {
     int r0 = gen_rows(n);
-    if (const char* e = std::getenv("FDES_GEN_TILE_ROWS")) { // measurement knob: smaller tiles where the default would do (profiles/r05_smaller_tiles.txt)
+    if (const char* e = std::getenv("FDES_GEN_TILE_ROWS")) { // measurement knob: smaller tiles where the default would do
         const int v = std::atoi(e);
         if ((v == 2 || v == 4) && v < r0) r0 = v;
     }
+    const char* pt = std::getenv("FDES_GEN_PARTIAL_TILES");
+    if (nrows < 1) return 0;
+    if (pt && pt[0] == '1') return r0;
     for (int r = r0; r >= 2; r >>= 1)
         if (nrows % r == 0) return r;
-    return 0;
+    return (pt && pt[0] == '0') ? 0 : r0;
 }
 bool gen_pass_compiled_in(int n) { return FDES_GEN_SPECIALISED && gen_specialised(n); }
 int gen_pass_threads(int n) { return gen_threads(n); }

@@ -108,14 +108,15 @@ def test_mixed_radix_source_compiles_under_hiprtc(n, ept):
 
 
 def test_which_grids_run_the_fused_loop():
-    """fdes_grid_backend (host only): powers of two and lengths 2^a 3^b 5^c 7^d 11^e 13^f in [256, 4096] run the fused loop (2) -
-    also where the tile rows of a mixed-radix length (8 up to 512 points, 4 up to 2048) do not divide the other dimension: smaller
-    tiles then (500^2; 750^2 = 2 nx of a .qsc with an odd nx); a prime factor above 13, an odd length, a length beyond 8192, or a
-    mixed-radix length beside a power of two whose row group does not divide it stay on rocFFT (1), as does option fft = 1."""
+    """fdes_grid_backend (host only): powers of two and lengths 2^a 3^b 5^c 7^d 11^e 13^f in [256, 4096], odd ones included, run the
+    fused loop (2) - also where the tile rows of a mixed-radix length (8 up to 512 points, 4 up to 2048) do not divide the other
+    dimension: smaller tiles then (500^2; 750^2 = 2 nx of a .qsc with an odd nx), a partial last tile for odd row counts (375^2,
+    1001^2); a prime factor above 13, a length below 256 or beyond 8192, or a length beside a power of two whose row group does
+    not divide it stay on rocFFT (1), as does option fft = 1."""
     lib = fdes_amd.load_library()
-    for m in (256, 320, 500, 572, 750, 800, 1000, 1100, 1250, 1430, 2002, 2048, 2288, 3000, 3300, 4000, 4096):
+    for m in (256, 320, 375, 500, 572, 750, 800, 1000, 1001, 1100, 1125, 1250, 1430, 2002, 2048, 2288, 3000, 3003, 3300, 4000, 4096):
         assert lib.fdes_grid_backend(m, m, 0) == 2, m
-    for m in (250, 374, 375, 2006, 3002, 4100, 8192):
+    for m in (250, 255, 374, 999, 2006, 3002, 4100, 8192):
         assert lib.fdes_grid_backend(m, m, 0) == 1, m
     assert lib.fdes_grid_backend(450, 4096, 0) == 2 and lib.fdes_grid_backend(500, 512, 0) == 2 and lib.fdes_grid_backend(1100, 572, 0) == 2
     assert lib.fdes_grid_backend(750, 1024, 0) == 1 and lib.fdes_grid_backend(1000, 1000, 1) == 1

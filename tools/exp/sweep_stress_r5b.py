@@ -24,6 +24,7 @@ def smooth13(n):
 LENGTHS = [n for n in range(256, 4097, 2) if smooth13(n) and (n & (n - 1)) != 0]
 WITH_11_13 = [n for n in LENGTHS if n % 11 == 0 or n % 13 == 0]
 MOD4_2 = [n for n in LENGTHS if n % 4 == 2 and n <= 2048]
+ODD = [n for n in range(257, 4096, 2) if smooth13(n)]   # odd lengths (seeds from 2000 on): a partial last tile on both axes
 BIG = [n for n in range(4098, 8193, 2) if smooth13(n)]   # rows beyond 4096 points (kernels compiled at plan creation only): beside a short other axis, so that the oracle stays cheap
 worst = 0.0
 for seed in range(first, first + count):
@@ -31,8 +32,11 @@ for seed in range(first, first + count):
     pool = [LENGTHS, WITH_11_13, MOD4_2][int(rng.integers(0, 3))]
     m1 = int(rng.choice(pool))
     m2 = m1
-    big_case = seed >= 1000   # seeds from 1000 on: one axis beyond 4096 points
-    if big_case:
+    big_case = 1000 <= seed < 2000   # seeds 1000 ... 1999: one axis beyond 4096 points
+    if seed >= 2000:
+        m1 = int(rng.choice(ODD))
+        m2 = m1 if rng.integers(0, 2) else int(rng.choice([n for n in ODD if max(n, m1) <= 3 * min(n, m1)]))
+    elif big_case:
         m1 = int(rng.choice(BIG))
         for _ in range(200):
             c = int(rng.choice([256, 320, 400, 500, 512, 572, 640, 750, 800, 1000, 1024]))
