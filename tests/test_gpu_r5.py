@@ -168,8 +168,8 @@ def test_run_time_compiled_kernels_whole_driver_and_mixed_axes(oracle, tmp_path,
     eng.close()
 
 
-@pytest.mark.parametrize("m,nz,jit", [(750, 2, 0), pytest.param(750, 1, 1, marks=full_only), pytest.param(500, 1, 0, marks=full_only), (500, 2, 1), (1250, 1, 1),
-                                      (375, 2, 1), (1001, 1, 0), pytest.param(625, 1, 1, marks=full_only), (1125, 2, 1)])   # odd lengths: 375 = 3 * 5^3, 1001 = 7 * 11 * 13, 1125 = 9 * 125
+@pytest.mark.parametrize("m,nz,jit", [(750, 2, 0), pytest.param(750, 1, 1, marks=full_only), pytest.param(500, 1, 0, marks=full_only), (500, 2, 1), pytest.param(1250, 1, 1, marks=full_only),
+                                      (375, 2, 1), (1001, 1, 0), pytest.param(625, 1, 1, marks=full_only), pytest.param(1125, 2, 1, marks=full_only)])   # odd lengths: 375 = 3 * 5^3, 1001 = 7 * 11 * 13, 1125 = 9 * 125
 def test_grids_that_the_tile_rows_do_not_divide(oracle, tmp_path, monkeypatch, m, nz, jit):
     """A mixed-radix row length has tiles of 8 (up to 512 points), 4 (up to 2048) or 2 rows; until round 5 a grid whose other
     dimension that number does not divide left the fused loop (750^2 and 1250^2: m = 2 nx of a .qsc with an odd nx,
@@ -336,7 +336,7 @@ pl.close(); eng.close()
 '''
 
 
-@pytest.mark.parametrize("stages", ["10,10,11", "5,20,11", "11,4,5,5"])
+@pytest.mark.parametrize("stages", [pytest.param("10,10,11", marks=full_only), pytest.param("5,20,11", marks=full_only), "11,4,5,5"])
 def test_run_time_compilation_with_given_stage_orders(tmp_path, stages):
     """FDES_JIT_STAGES (a tuning knob) gives the stage radices of a compilation outright: any order of supported radices whose
     product is the length - three or four stages, prime and composite radices anywhere - must give the same physics (1100^2 slice
