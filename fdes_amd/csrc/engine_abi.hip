@@ -138,7 +138,7 @@ int fdes_plan_get_images(fdes_plan* pl, float* image)
 int fdes_grid_backend(int m1, int m2, int fft_option)
 {
     if (m1 < 1 || m2 < 1) return FDES_EINVAL;
-    if ((m1 > 4096 || m2 > 4096) && !gen_jit_default_on()) return 1; // rows beyond 4096 points run compiled-at-plan-creation kernels only
+    if (!gen_jit_default_on() && ((gen_pass_supported_len(m1) && gen_pass_needs_compiled(m1)) || (gen_pass_supported_len(m2) && gen_pass_needs_compiled(m2)))) return 1; // such rows run compiled-at-plan-creation kernels only
     return (fft_option != 1 && Fft2D::lds_supported(m1, m2)) ? 2 : 1;
 }
 int fdes_plan_fft_backend(const fdes_plan* pl) { return live_plan(pl) ? pl->fft->backend : FDES_EINVAL; }

@@ -61,9 +61,9 @@ int Fft2D::create(int m1_, int m2_, int opt, hipStream_t st, std::string* err, b
             jit_y = (m2 == m1) ? jit_x : gen_jit_prepare(m2, rows_y, &jit_note);
             if (!jit_note.empty() && std::getenv("FDES_JIT_VERBOSE")) std::fprintf(stderr, "  FDES: run-time-length kernels (%s)\n", jit_note.c_str());
         }
-        // rows beyond 4096 points exist as compiled kernels only: without them the grid takes rocFFT like any unsupported size
-        if ((m1 > 4096 && rows_x > 0 && !jit_x) || (m2 > 4096 && rows_y > 0 && !jit_y)) {
-            if (opt == 2) { if (err) *err = "rows beyond 4096 points need their kernels compiled at plan creation (hipRTC; option jit, FDES_JIT): " + jit_note; return -1; }
+        // rows beyond 4096 points (and lengths with a factor 17, 19, 23) exist as compiled kernels only: without them the grid takes rocFFT like any unsupported size
+        if ((gen_pass_needs_compiled(m1) && rows_x > 0 && !jit_x) || (gen_pass_needs_compiled(m2) && rows_y > 0 && !jit_y)) {
+            if (opt == 2) { if (err) *err = "rows beyond 4096 points and lengths with a factor 17, 19 or 23 need their kernels compiled at plan creation (hipRTC; option jit, FDES_JIT): " + jit_note; return -1; }
             backend = 1;
             jit_x = jit_y = nullptr;
             rows_x = rows_y = 0;

@@ -40,7 +40,7 @@ namespace {
 #include "fft_dev.inc"
 
 constexpr int kGenMaxLen = 8192; // longest row: a tile of two rows (one image) is 128 KiB of LDS
-constexpr int kRxMax = 13; // largest radix of a stage: registers of one butterfly (run-time-length kernels)
+constexpr int kRxMax = 23; // largest radix of a stage: registers of one butterfly (13 in the run-time-length kernels; 17, 19, 23: compile-time kernels only)
 
 struct GenFac {
     int n = 0;       // row length
@@ -98,16 +98,16 @@ __host__ __device__ constexpr bool gen_three_stages(int n, int (&r)[3])
 // (profiles/r05_rows_beyond_4096.txt: 5000, 4800, 8000, 3840)
 __host__ __device__ constexpr bool gen_auto_three_stages(int n, int (&r)[3])
 {
-    const int S[14] = {25, 20, 16, 15, 13, 12, 11, 10, 8, 7, 5, 4, 3, 2};
+    const int S[17] = {25, 23, 20, 19, 17, 16, 15, 13, 12, 11, 10, 8, 7, 5, 4, 3, 2};
     const int evenpref[7] = {10, 12, 8, 16, 20, 4, 2};
     long best = -1;
-    for (int ia = 0; ia < 14; ia++)
-        for (int ib = 0; ib < 14; ib++) {
+    for (int ia = 0; ia < 17; ia++)
+        for (int ib = 0; ib < 17; ib++) {
             const int a = S[ia], b = S[ib];
             if (n % (a * b) != 0) continue;
             const int c = n / (a * b);
             bool ok = false;
-            for (int ic = 0; ic < 14; ic++) ok = ok || S[ic] == c;
+            for (int ic = 0; ic < 17; ic++) ok = ok || S[ic] == c;
             if (!ok) continue;
             const int mx = a > b ? (a > c ? a : c) : (b > c ? b : c);
             int apref = 0; // larger is better
@@ -126,29 +126,29 @@ __host__ __device__ constexpr bool gen_auto_three_stages(int n, int (&r)[3])
 // run-time compilation only): smallest largest radix, odd first radix where one exists, then the larger second radix
 __host__ __device__ constexpr bool gen_auto_four_stages(int n, int (&r)[4])
 {
-    const int S[14] = {25, 20, 16, 15, 13, 12, 11, 10, 8, 7, 5, 4, 3, 2};
+    const int S[17] = {25, 23, 20, 19, 17, 16, 15, 13, 12, 11, 10, 8, 7, 5, 4, 3, 2};
     if (n % 64 == 0) { // measured (profiles/r05_rows_beyond_4096.txt): a x 16 x c x 4 with a medium first radix - 8192 = 8 x 16 x 16 x 4 (+24 % over 2 x 16 x 16 x 16),
                        // 6144 = 12 x 16 x 8 x 4 (+11 % over 8 x 12 x 8 x 8), 7680 = 12 x 16 x 10 x 4 (+22 %), 7168 = 7 x 16 x 16 x 4; a first radix of 16 loses 5 ... 20 %
-        const int pref[14] = {12, 10, 8, 15, 7, 5, 13, 11, 3, 20, 25, 16, 4, 2};
+        const int pref[17] = {12, 10, 8, 15, 7, 5, 13, 11, 3, 20, 25, 17, 19, 23, 16, 4, 2};
         const int rest = n / 64;
-        for (int ia = 0; ia < 14; ia++) {
+        for (int ia = 0; ia < 17; ia++) {
             const int a = pref[ia];
             if (rest % a != 0) continue;
             const int c = rest / a;
             bool ok = false;
-            for (int ic = 0; ic < 14; ic++) ok = ok || S[ic] == c;
+            for (int ic = 0; ic < 17; ic++) ok = ok || S[ic] == c;
             if (ok) { r[0] = a; r[1] = 16; r[2] = c; r[3] = 4; return true; }
         }
     }
     long best = -1;
-    for (int ia = 0; ia < 14; ia++)
-        for (int ib = 0; ib < 14; ib++)
-            for (int ic = 0; ic < 14; ic++) {
+    for (int ia = 0; ia < 17; ia++)
+        for (int ib = 0; ib < 17; ib++)
+            for (int ic = 0; ic < 17; ic++) {
                 const int a = S[ia], b = S[ib], c = S[ic];
                 if (n % (a * b * c) != 0) continue;
                 const int d = n / (a * b * c);
                 bool ok = false;
-                for (int id = 0; id < 14; id++) ok = ok || S[id] == d;
+                for (int id = 0; id < 17; id++) ok = ok || S[id] == d;
                 if (!ok) continue;
                 int mx = a > b ? a : b;
                 mx = mx > c ? mx : c;
@@ -159,7 +159,7 @@ __host__ __device__ constexpr bool gen_auto_four_stages(int n, int (&r)[4])
     return best >= 0;
 }
 
-// factors and stage tables of an n-point row; false if n has a prime factor above 13 or more than 8 stages
+// factors and stage tables of an n-point row; false if n has a prime factor above 23 or more than 8 stages
 __host__ __device__ constexpr bool factorize(int n, GenFac& f)
 {
     f.n = n;
@@ -184,8 +184,8 @@ __host__ __device__ constexpr bool factorize(int n, GenFac& f)
     }
 #endif
     // large radices first: fewer stages (each stage is one trip of the tile through LDS)
-    const int cand[9] = {13, 11, 10, 8, 7, 5, 4, 3, 2}; // (round 5, second half: 11 and 13)
-    for (int ci = 0; ci < 9; ci++)
+    const int cand[12] = {23, 19, 17, 13, 11, 10, 8, 7, 5, 4, 3, 2}; // (round 5, second half: 11 and 13; 17, 19, 23 for the compile-time kernels only: gen_needs_compiled)
+    for (int ci = 0; ci < 12; ci++)
         while (m % cand[ci] == 0 && m > 1) {
             if (f.nf == 8) return false;
             f.radix[f.nf++] = cand[ci];
@@ -406,9 +406,18 @@ constexpr double kCos11[5] = {0.84125353283118116886, 0.41541501300188642553, -0
 constexpr double kSin11[5] = {0.54064081745559758211, 0.90963199535451837141, 0.98982144188093273238, 0.75574957435425828377, 0.28173255684142969771};
 constexpr double kCos13[6] = {0.88545602565320989590, 0.56806474673115580251, 0.12053668025532305335, -0.35460488704253562597, -0.74851074817110109863, -0.97094181742605202716};
 constexpr double kSin13[6] = {0.46472317204376854566, 0.82298386589365639458, 0.99270887409805399280, 0.93501624268541482344, 0.66312265824079520238, 0.23931566428755776715};
+// 17, 19, 23 (lengths such as 1088 = 64 x 17, 1216 = 64 x 19, 1472 = 64 x 23): in the compile-time kernels only, i.e. compiled at plan creation
+constexpr double kCos17[8] = {0.93247222940435580457, 0.73900891722065911592, 0.4457383557765382674, 0.09226835946330199524, -0.27366299007208286354, -0.60263463637925638918, -0.85021713572961415213, -0.98297309968390177828};
+constexpr double kSin17[8] = {0.36124166618715294874, 0.67369564364655721171, 0.89516329135506232207, 0.99573417629503452187, 0.96182564317281907041, 0.79801722728023950333, 0.52643216287735580024, 0.18374951781657033157};
+constexpr double kCos19[9] = {0.94581724170063467902, 0.78914050939639359922, 0.54694815812242687471, 0.24548548714079914892, -0.0825793454723323246, -0.40169542465296945752, -0.67728157162574107476, -0.87947375120648907139, -0.9863613034027223736};
+constexpr double kSin19[9] = {0.32469946920468348741, 0.61421271268966781744, 0.83716647826252857481, 0.96940026593933041674, 0.99658449300666984982, 0.91577332665505743992, 0.73572391067313162477, 0.47594739303707354443, 0.16459459028073389414};
+constexpr double kCos23[11] = {0.96291728734779929502, 0.85441940454648855255, 0.68255314321865408287, 0.46006503773115212604, 0.20345601305263378988, -0.068242413364670975921, -0.33487961217098615196, -0.57668032211486714125, -0.77571129070441980704, -0.91721130150545301784, -0.99068594603633075234};
+constexpr double kSin23[11] = {0.26979677115702427125, 0.51958395003543357813, 0.73083596427812410165, 0.88788521840237523498, 0.97908408768232287563, 0.99766876919053919845, 0.94226092211882049562, 0.81696989301044201697, 0.63108794432605278937, 0.398401089846241458, 0.13616664909624659076};
+template <int P> __host__ __device__ constexpr double prime_cos(int q) { return P == 11 ? kCos11[q] : (P == 13 ? kCos13[q] : (P == 17 ? kCos17[q] : (P == 19 ? kCos19[q] : kCos23[q]))); }
+template <int P> __host__ __device__ constexpr double prime_sin(int q) { return P == 11 ? kSin11[q] : (P == 13 ? kSin13[q] : (P == 17 ? kSin17[q] : (P == 19 ? kSin19[q] : kSin23[q]))); }
 template <int P> __device__ __forceinline__ void dft_prime(cf (&x)[kRxMax], float s)
 {
-    static_assert(P == 11 || P == 13, "radix");
+    static_assert(P == 11 || P == 13 || P == 17 || P == 19 || P == 23, "radix");
     constexpr int H = (P - 1) / 2;
     cf a[H], b[H];
 #pragma unroll
@@ -427,8 +436,8 @@ template <int P> __device__ __forceinline__ void dft_prime(cf (&x)[kRxMax], floa
         for (int j = 1; j <= H; j++) {
             const int q = (j * k) % P;            // angle 2 pi q / P; cos(2 pi q / P) = cos(2 pi (P - q) / P), sin changes sign
             const int qq = q <= H ? q : P - q;
-            const float c = (float)(P == 11 ? kCos11[qq - 1] : kCos13[qq - 1]);
-            const float sn = (float)(P == 11 ? kSin11[qq - 1] : kSin13[qq - 1]) * (q <= H ? 1.f : -1.f);
+            const float c = (float)prime_cos<P>(qq - 1);
+            const float sn = (float)prime_sin<P>(qq - 1) * (q <= H ? 1.f : -1.f);
             mk = mk + a[j - 1] * c;
             nk = nk + b[j - 1] * sn;
         }
@@ -470,7 +479,7 @@ __device__ __forceinline__ void gen_stage(const cf* __restrict__ src, cf* __rest
         if constexpr (RX == 7) dft7(x, s);
         if constexpr (RX == 8) dft8(x, s);
         if constexpr (RX == 10) dft10(x, s);
-        if constexpr (RX == 11 || RX == 13) dft_prime<RX>(x, s);
+        if constexpr (RX == 11 || RX == 13 || RX == 17 || RX == 19 || RX == 23) dft_prime<RX>(x, s);
         cf* __restrict__ out = drow + (j - k) * RX + k;
 #pragma unroll
         for (int i = 0; i < RX; i++) out[i * Ns] = x[i];
@@ -581,14 +590,14 @@ template <int RX> __host__ __device__ constexpr int rdx_slot(int i)
 template <int RX> __device__ __forceinline__ void rdx_dft(cf (&x)[RX], float s)
 {
     if constexpr (RX == 2 || RX == 3 || RX == 4 || RX == 5) pdft<RX, 1>(x, s);
-    else if constexpr (RX == 7 || RX == 8 || RX == 10 || RX == 11 || RX == 13) {
+    else if constexpr (RX == 7 || RX == 8 || RX == 10 || RX == 11 || RX == 13 || RX == 17 || RX == 19 || RX == 23) {
         cf t[kRxMax];
 #pragma unroll
         for (int i = 0; i < RX; i++) t[i] = x[i];
         if constexpr (RX == 7) dft7(t, s);
         if constexpr (RX == 8) dft8(t, s);
         if constexpr (RX == 10) dft10(t, s);
-        if constexpr (RX == 11 || RX == 13) dft_prime<RX>(t, s);
+        if constexpr (RX == 11 || RX == 13 || RX == 17 || RX == 19 || RX == 23) dft_prime<RX>(t, s);
 #pragma unroll
         for (int i = 0; i < RX; i++) x[i] = t[i];
     } else {
@@ -792,6 +801,11 @@ __device__ __forceinline__ void gen_fft(cf*& cur, cf*& other, const cf* __restri
         case 8: gen_stage<8>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         case 11: gen_stage<11>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         case 13: gen_stage<13>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+#ifdef FDES_GEN_JIT_N // (17, 19, 23: kernels compiled at plan creation only - lengths up to 512 points run their stages between two images, through here)
+        case 17: gen_stage<17>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+        case 19: gen_stage<19>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+        case 23: gen_stage<23>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
+#endif
         default: gen_stage<10>(cur, other, twl, F.n, F.nbf[q], F.ns[q], F.tws[q], F.magic[q], s, row, jt, tpr); break;
         }
         // a stage of a row touches that row only: with 64 threads per row (rows up to 512 points) a row belongs to ONE wave,
@@ -1325,14 +1339,19 @@ template <int NC, int EPT> hipError_t gdispatch(int pre, int mid, int post, bool
 
 } // namespace
 
+// lengths that exist as compile-time kernels only, i.e. compiled at plan creation (gen_jit.cpp): rows beyond 4096 points (one tile image of
+// two rows; the run-time-length form needs two) and lengths with a factor 17, 19 or 23 (the run-time-length kernels stop at radix 13)
+bool gen_pass_needs_compiled(int n) { return n > 4096 || n % 17 == 0 || n % 19 == 0 || n % 23 == 0; }
+
 bool gen_pass_supported_len(int n)
 {
-    if (n > 4096) { // rows of 4098 ... 8192 points (round 5): one tile image of two rows, compile-time kernels only - i.e. compiled at plan creation
+    if (n > 4096) { // rows of 4098 ... 8192 points (round 5)
         GenFac f8;
         return n <= kGenMaxLen && n % 2 == 0 && gen_jit_available() && factorize(n, f8);
     }
     if (n < 256) return false;
     if ((n & (n - 1)) == 0) return false; // powers of two have kernels of their own
+    if (gen_pass_needs_compiled(n) && !gen_jit_available()) return false;
     GenFac f;
     return factorize(n, f);
 }
@@ -1407,7 +1426,7 @@ hipError_t gen_pass(int n, int pre, int mid, int post, bool st_t, const PassArgs
         if (n == 3600) return gdispatch<3600, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
         if (n == 4000) return gdispatch<4000, (FDES_GEN_ROWS4 ? 32 : 16)>(pre, mid, post, st_t, a, f, st);
     }
-    if (n > 4096) return hipErrorInvalidValue; // (rows beyond 4096 points have no run-time-length form: Fft2D::create takes rocFFT when their compilation fails)
+    if (gen_pass_needs_compiled(n)) return hipErrorInvalidValue; // (no run-time-length form: Fft2D::create takes rocFFT when the compilation fails)
     if (ept <= 8) return gdispatch<0, 8>(pre, mid, post, st_t, a, f, st);
     if (ept <= 16) return gdispatch<0, 16>(pre, mid, post, st_t, a, f, st);
     return hipErrorInvalidValue;

@@ -120,6 +120,7 @@ hipError_t wave_pass(int n, int pre, int mid, int post, bool store_transposed, c
 // LDS-resident mixed-radix passes for row lengths 2^a 3^b 5^c 7^d in [256, 4096] that are not powers of two (fft_gen.hip);
 // their twiddle table is the n roots of unity W_n^k (float2 as 2 floats)
 bool gen_pass_supported_len(int n);
+bool gen_pass_needs_compiled(int n); // ... only as kernels compiled at plan creation (rows beyond 4096 points, factors 17 / 19 / 23)
 int gen_pass_rows(int n);
 int gen_pass_tile_rows(int n, int nrows);
 void gen_pass_twiddles(int n, float* tw);

@@ -127,13 +127,13 @@ const std::vector<char>* code_for(int n, int rows, std::string* note)
     const std::string o_n = "-DFDES_GEN_JIT_N=" + std::to_string(n), o_e = "-DFDES_GEN_JIT_EPT=" + std::to_string(ept_of(n, rows)),
                       o_r = "-DFDES_GEN_JIT_ROWS=" + std::to_string(rows);
     // tuning knob: FDES_JIT_STAGES=a,b,c[,d] gives the stage radices of every compilation of this process outright (product = the length,
-    // radices out of 2 ... 5, 7, 8, 10 ... 13, 15, 16, 20, 25; anything else is ignored); part of the cache key like every option
+    // radices out of 2 ... 5, 7, 8, 10 ... 13, 15, 16, 17, 19, 20, 23, 25; anything else is ignored); part of the cache key like every option
     std::string o_s[4];
     int nstage_opts = 0;
     if (const char* e = std::getenv("FDES_JIT_STAGES")) {
         int r[4] = {0, 0, 0, 1};
         const int got = std::sscanf(e, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]);
-        auto okr = [](int v) { for (int c : {2, 3, 4, 5, 7, 8, 10, 11, 12, 13, 15, 16, 20, 25}) if (v == c) return true; return false; };
+        auto okr = [](int v) { for (int c : {2, 3, 4, 5, 7, 8, 10, 11, 12, 13, 15, 16, 17, 19, 20, 23, 25}) if (v == c) return true; return false; };
         if (got >= 3 && okr(r[0]) && okr(r[1]) && okr(r[2]) && (got == 3 || okr(r[3])) && (long)r[0] * r[1] * r[2] * (got == 3 ? 1 : r[3]) == n) {
             if (got == 3) r[3] = 1;
             for (int q = 0; q < 4; q++) o_s[q] = "-DFDES_GEN_JIT_R" + std::to_string(q) + "=" + std::to_string(r[q]);

@@ -231,7 +231,7 @@ int fdes_plan_sync(fdes_plan* plan);
 /* 1: generic slice loop on rocFFT + point-wise kernels; 2: fused LDS-pass slice loop. */
 int fdes_plan_fft_backend(const fdes_plan* plan);
 /* Grid axes (0, 1 or 2) of a fused plan whose row passes run kernels compiled for that length at plan creation (hipRTC; option
-   "jit", FDES_JIT=0 turns it off): lengths 2^a 3^b 5^c 7^d 11^e 13^f without compiled-in kernels (and every row of 4098 ... 8192 points) - cufftPlan2d serves any size
+   "jit", FDES_JIT=0 turns it off): lengths 2^a 3^b 5^c 7^d 11^e 13^f without compiled-in kernels (and every row of 4098 ... 8192 points or with a factor 17, 19, 23) - cufftPlan2d serves any size
    alike (src/paramStructure.cu:676-679), here the compile-time form of the row passes is about twice as fast as the form that
    takes the length at run time.  0 for the power-of-two grids and the lengths whose kernels are part of the library. */
 int fdes_plan_jit_kernels(const fdes_plan* plan);

@@ -391,8 +391,8 @@ def test_fused_path_is_bit_reproducible(kw):
     """Two runs of the same simulation on the fused path give the same bits: the deposits go through single-wave LDS
     atomics in sorted order, lanes are dealt round-robin and folded in lane order, graphs replay fixed launch sequences,
     and the CBED probe norm is a fixed-order two-stage sum (round 1: float atomicAdd across blocks).  Round 3: the same
-    for the mixed-radix grids (320, 800), the one-wave-per-row passes (2048) and the rocFFT path (fft = 1, and 374 = 2 11 17
-    which no hand-written kernel serves): its deposit now adds the atoms in sorted order through an LDS tile, and the
+    for the mixed-radix grids (320, 800), the one-wave-per-row passes (2048) and the rocFFT path (fft = 1; 374 = 2 11 17
+    has kernels only when they are compiled at plan creation, which this suite turns off): its deposit now adds the atoms in sorted order through an LDS tile, and the
     potential output of print_level 1 with it."""
     kw = dict(kw)
     fft = kw.pop("fft", 0)

@@ -349,3 +349,46 @@ def test_run_time_compilation_with_given_stage_orders(tmp_path, stages):
     e = float(r.stdout.split("E")[-1])
     print(f"[parity] 1100^2 slice loop with stages {stages}: E = {e:.3e}")
     assert e <= 1e-5
+
+
+@pytest.mark.parametrize("m,nz", [(1088, 1), (608, 2), (475, 2), pytest.param(736, 1, marks=full_only)])   # (475 = 19 * 25: up to 512 points the stages run between two tile images - a dispatch of its own, which the stress sweep found without these radices)
+def test_lengths_with_factors_17_19_23(oracle, tmp_path, monkeypatch, m, nz):
+    """1088 = 64 * 17, 608 = 32 * 19, 736 = 32 * 23: radices 17, 19 and 23 exist in the compile-time kernels only, so these
+    lengths run the fused loop on kernels compiled at plan creation (as the rows beyond 4096 points) and rocFFT with jit = 0:
+    2-D FFT against numpy, slice loop and potential against the float64 oracle."""
+    monkeypatch.setenv("FDES_JIT_CACHE", str(tmp_path / "jit"))
+    rng = np.random.default_rng(17)
+    f = (rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))).astype(np.complex64)
+    eng = fdes_amd.Engine(0, jit=1)
+    for inv in (False, True):
+        o, used = eng.fft2(f, inv, backend=0)
+        assert used == 2
+        ref = np.fft.ifft2(f.astype(np.complex128)) * f.size if inv else np.fft.fft2(f.astype(np.complex128))
+        e = relerr(o, ref)
+        print(f"[parity] fft {m}^2 inv={inv}: rel L2 {e:.3e}")
+        assert e < 7e-7
+    eng.close()
+    hp, at = S.case_tiny(m=m, m3=4, nz=nz, nat=200, tilt=True, seed=19)
+    fdes_amd.consistent(hp)
+    q, _ = oracle.sub_sliced(hp)
+    ref = oracle.wave(q, at, 0, 0, prec="f64")
+    r32 = oracle.wave(q, at, 0, 0, prec="f32")
+    for skip in (0, 1):
+        eng = fdes_amd.Engine(0, skip_empty=skip, jit=1)
+        pl = eng.plan(hp, at)
+        assert pl.fft_backend() == 2 and pl.jit_kernels() == 2
+        check(pl.tap_wave(0, 0), ref, r32, 1e-5, f"{m}^2 (radix {17 if m % 17 == 0 else (19 if m % 19 == 0 else 23)}) skip_empty={skip}")
+        if skip == 0:
+            xyz = oracle.config_coords(q, at, 0, -1)
+            for sl in range(q.c.m3):
+                Vref = oracle.phase_grating(q, at, xyz, sl, "f64")
+                if np.abs(Vref).max() > 0:
+                    check(pl.tap_potential(0, 0, sl), Vref, None, 1e-5, f"{m}^2 potential s={sl}")
+                    break
+        pl.close()
+        eng.close()
+    eng = fdes_amd.Engine(0, jit=0)
+    pl = eng.plan(hp, at)
+    assert pl.fft_backend() == 1
+    pl.close()
+    eng.close()

@@ -116,7 +116,7 @@ def test_which_grids_run_the_fused_loop():
     lib = fdes_amd.load_library()
     for m in (256, 320, 375, 500, 572, 750, 800, 1000, 1001, 1100, 1125, 1250, 1430, 2002, 2048, 2288, 3000, 3003, 3300, 4000, 4096):
         assert lib.fdes_grid_backend(m, m, 0) == 2, m
-    for m in (250, 255, 374, 999, 2006, 3002, 4100, 8192):
+    for m in (250, 255, 374, 999, 1450, 3002, 4100, 8192):   # (374 = 2 * 11 * 17 and 2006 = 2 * 17 * 59: see below)
         assert lib.fdes_grid_backend(m, m, 0) == 1, m
     assert lib.fdes_grid_backend(450, 4096, 0) == 2 and lib.fdes_grid_backend(500, 512, 0) == 2 and lib.fdes_grid_backend(1100, 572, 0) == 2
     assert lib.fdes_grid_backend(750, 1024, 0) == 1 and lib.fdes_grid_backend(1000, 1000, 1) == 1
@@ -124,8 +124,9 @@ def test_which_grids_run_the_fused_loop():
     # (this suite runs with FDES_JIT=0, tests/conftest.py: the query says 1 here) and libhiprtc loads
     code = ("import sys; sys.path.insert(0, %r); import fdes_amd\n"
             "lib = fdes_amd.load_library()\n"
-            "print([lib.fdes_grid_backend(m, m, 0) for m in (8192, 5000, 6144, 4100, 8194, 9000)], lib.fdes_grid_backend(8192, 256, 0))\n" % ROOT)
-    for jit, want in (("0", "[1, 1, 1, 1, 1, 1] 1"), ("1", "[2, 2, 2, 1, 1, 1] 2")):
+            "print([lib.fdes_grid_backend(m, m, 0) for m in (8192, 5000, 6144, 4100, 8194, 9000, 1088, 1216, 736, 1450)], lib.fdes_grid_backend(8192, 256, 0))\n" % ROOT)
+    # (1088 = 64 * 17, 1216 = 64 * 19, 736 = 32 * 23: radices of the compile-time kernels only; 1450 = 2 * 25 * 29: rocFFT)
+    for jit, want in (("0", "[1, 1, 1, 1, 1, 1, 1, 1, 1, 1] 1"), ("1", "[2, 2, 2, 1, 1, 1, 2, 2, 2, 1] 2")):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FDES_JIT=jit), capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and want in r.stdout, (jit, r.stdout, r.stderr)
 

@@ -24,6 +24,14 @@ def smooth13(n):
 LENGTHS = [n for n in range(256, 4097, 2) if smooth13(n) and (n & (n - 1)) != 0]
 WITH_11_13 = [n for n in LENGTHS if n % 11 == 0 or n % 13 == 0]
 MOD4_2 = [n for n in LENGTHS if n % 4 == 2 and n <= 2048]
+def smooth23(n):
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
+P23 = [n for n in range(256, 4097) if smooth23(n) and not smooth13(n)]   # a factor 17, 19 or 23 (seeds from 3000 on): compile-time kernels only
 ODD = [n for n in range(257, 4096, 2) if smooth13(n)]   # odd lengths (seeds from 2000 on): a partial last tile on both axes
 BIG = [n for n in range(4098, 8193, 2) if smooth13(n)]   # rows beyond 4096 points (kernels compiled at plan creation only): beside a short other axis, so that the oracle stays cheap
 worst = 0.0
@@ -33,7 +41,16 @@ for seed in range(first, first + count):
     m1 = int(rng.choice(pool))
     m2 = m1
     big_case = 1000 <= seed < 2000   # seeds 1000 ... 1999: one axis beyond 4096 points
-    if seed >= 2000:
+    if seed >= 3000:
+        m1 = int(rng.choice(P23))
+        m2 = m1
+        if rng.integers(0, 2):
+            for _ in range(100):
+                c = int(rng.choice(P23 + LENGTHS))
+                if lib.fdes_grid_backend(m1, c, 0) == 2 and max(m1, c) <= 3 * min(m1, c):
+                    m2 = c
+                    break
+    elif seed >= 2000:
         m1 = int(rng.choice(ODD))
         m2 = m1 if rng.integers(0, 2) else int(rng.choice([n for n in ODD if max(n, m1) <= 3 * min(n, m1)]))
     elif big_case:
@@ -60,7 +77,7 @@ for seed in range(first, first + count):
         kw["n3"] = min(kw["n3"], 2); kw["frPh"] = min(kw["frPh"], 2); kw["m3"] = min(kw["m3"], 4)
     if big >= 2600:
         kw["n3"] = 1; kw["sub"] = 1
-    opts = dict(gang=int(rng.choice([-1, -1, 0, 2, 4, 8])), lanes=int(rng.choice([0, 0, 1, 2, 3])), skip_empty=int(rng.integers(0, 2)), jit=1 if big_case else int(rng.integers(0, 2)))
+    opts = dict(gang=int(rng.choice([-1, -1, 0, 2, 4, 8])), lanes=int(rng.choice([0, 0, 1, 2, 3])), skip_empty=int(rng.integers(0, 2)), jit=1 if (big_case or seed >= 3000) else int(rng.integers(0, 2)))
     hp, at = S.case_tiny(**kw)
     fdes_amd.consistent(hp)
     eng = fdes_amd.Engine(0, **opts)
