@@ -197,7 +197,7 @@ __host__ __device__ constexpr bool factorize(int n, GenFac& f)
         // chosen as the hand-measured table above suggests (gen_auto_three_stages)
         int cr[3] = {0, 0, 0}, c4[4] = {0, 0, 0, 0};
 #ifdef FDES_GEN_JIT_R0 // tuning knob (FDES_JIT_STAGES=a,b,c[,d] -> gen_jit.cpp): the stage radices of this compilation, given outright
-        if (n == FDES_GEN_JIT_N && (long)FDES_GEN_JIT_R0 * FDES_GEN_JIT_R1 * FDES_GEN_JIT_R2 * FDES_GEN_JIT_R3 == n) {
+        if (n == FDES_GEN_JIT_N && n > 512 && (long)FDES_GEN_JIT_R0 * FDES_GEN_JIT_R1 * FDES_GEN_JIT_R2 * FDES_GEN_JIT_R3 == n) { // (beyond 512 points only: the two-image stages of shorter rows know the single radices alone)
             c4[0] = FDES_GEN_JIT_R0; c4[1] = FDES_GEN_JIT_R1; c4[2] = FDES_GEN_JIT_R2; c4[3] = FDES_GEN_JIT_R3;
             f.nf = FDES_GEN_JIT_R3 > 1 ? 4 : 3;
             for (int q = 0; q < 8; q++) f.radix[q] = q < f.nf ? c4[q] : 0;
