@@ -351,7 +351,7 @@ def test_run_time_compilation_with_given_stage_orders(tmp_path, stages):
     assert e <= 1e-5
 
 
-@pytest.mark.parametrize("m,nz", [(1088, 1), (608, 2), (475, 2), pytest.param(736, 1, marks=full_only)])   # (475 = 19 * 25: up to 512 points the stages run between two tile images - a dispatch of its own, which the stress sweep found without these radices)
+@pytest.mark.parametrize("m,nz", [(1088, 1), pytest.param(608, 2, marks=full_only), (475, 2), pytest.param(736, 1, marks=full_only)])   # (475 = 19 * 25: up to 512 points the stages run between two tile images - a dispatch of its own, which the stress sweep found without these radices)
 def test_lengths_with_factors_17_19_23(oracle, tmp_path, monkeypatch, m, nz):
     """1088 = 64 * 17, 608 = 32 * 19, 736 = 32 * 23: radices 17, 19 and 23 exist in the compile-time kernels only, so these
     lengths run the fused loop on kernels compiled at plan creation (as the rows beyond 4096 points) and rocFFT with jit = 0:
